@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s + achieved algorithmic GB/s of the ray-march hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one frame: one pass of the ray-march over every pixel of the viewport
+(BASELINE.json: bonsai 256^3 uint8 @ 1920x1080, benchmark parameters of src/main.rs:180-190
+with step 0.01, the reference's effective camera eye (0.5,0.5,1.5)).  The real .raw is not in
+the repository (.MISSING_LARGE_BLOBS), so the volume is volym_amd.synth.synth_bonsai(256).
+
+N > 1: the framebuffer is sharded by interleaved 16x16 screen tiles over the ranks, the volume
+is replicated, and every frame's shards are gathered to every rank over RCCL (all_gather) and
+assembled into a raster on rank 0; frame i's gather overlaps frame i+1's march (two buffers).
+Total work per step is fixed, so scaling is "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def build_scene(args):
+    from volym_amd import scene, synth
+    n = args.volume
+    raw, labels = synth.synth_bonsai(n, with_labels=True)
+    segments = [{"label_value": 2, "importance": 255}, {"label_value": 3, "importance": 0},
+                {"label_value": 4, "importance": 0}]
+    dims = (n, n, n)
+    volume = scene.prepare_volume(raw, dims, True)
+    importances = scene.prepare_volume(scene.map_segments_to_importance(labels, segments), dims, True)
+    params = scene.StateParameters.benchmark().replace(
+        raymarching_step_size=args.step, use_importance_rendering=1 if args.importance else 0,
+        use_cone_importance_check=1 if args.cone else 0)
+    state = scene.State.with_parameters(args.width / args.height, params)
+    state.update()   # the frame loop's orbit(0,0,0): eye -> (0.5,0.5,1.5)  (src/event_loop.rs:100)
+    return dims, volume, importances, scene.default_lut(), state
+
+
+def cpu_baseline(args, dims, volume, importances, lut, state, budget_s=12.0):
+    """The oracle (CPU restatement, NOT wgpu/lavapipe -- the reference cannot run here) timed on
+    the host cores over a bounded sample: every `stride`-th pixel row of the same frame."""
+    from oracle import oracle as O
+    cam = O.CameraUniforms.from_buffer_copy(bytes(state.camera_uniforms()))
+    par = O.Parameters.from_buffer_copy(bytes(state.parameter_uniforms()))
+    W, H = args.width, args.height
+    cores = os.cpu_count() or 1
+    filt = 1 if args.linear else 0
+    # probe 8 rows around the centre to size the sample
+    t0 = time.perf_counter()
+    O.render(volume, importances, dims, lut, cam, par, W, H, filter=filt, threads=cores, rows=(H // 2 - 4, H // 2 + 4),
+             want_f32=False)
+    per_row = (time.perf_counter() - t0) / 8.0
+    rows_budget = max(8, int(budget_s / max(per_row, 1e-6)))
+    if rows_budget >= H:
+        t0 = time.perf_counter()
+        _, _, k = O.render(volume, importances, dims, lut, cam, par, W, H, filter=filt, threads=cores, want_f32=False)
+        dt = time.perf_counter() - t0
+        rays, sample = W * H, "full %dx%d frame, 1 pass" % (W, H)
+    else:
+        stride = (H + rows_budget - 1) // rows_budget
+        rows = list(range(0, H, stride))
+        t0 = time.perf_counter()
+        k = None
+        for y in rows:
+            O.render(volume, importances, dims, lut, cam, par, W, H, filter=filt, threads=cores, rows=(y, y + 1), want_f32=False)
+        dt = time.perf_counter() - t0
+        rays, sample = W * len(rows), "every %d-th row of the %dx%d frame (%d rows)" % (stride, W, H, len(rows))
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": sample + "; CPU restatement (oracle/volym_oracle.c, gcc -O2), not wgpu/lavapipe"}, k
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--volume", type=int, default=256)
+    ap.add_argument("--step", type=float, default=0.01)
+    ap.add_argument("--kernel", type=int, default=1, help="0 direct (config 2), 1 macro-cell (config 3)")
+    ap.add_argument("--linear", action="store_true", help="trilinear volume filter (north_star mode)")
+    ap.add_argument("--importance", action="store_true")
+    ap.add_argument("--cone", action="store_true")
+    ap.add_argument("--xcd-bands", type=int, default=-1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from volym_amd import _lib, demo
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    dims, volume, importances, lut, state = build_scene(args)
+    W, H = args.width, args.height
+
+    ctx = demo.GpuContext(W, H, local_rank)
+    ctx.set_option(_lib.OPT_KERNEL, args.kernel)
+    if args.xcd_bands >= 0:
+        ctx.set_option(_lib.OPT_XCD_BANDS, args.xcd_bands)
+    ctx.set_shard(rank, world)
+    ctx.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
+    ctx.set_importances(importances, dims)
+    ctx.set_transfer_function(lut)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.update(state.camera_uniforms(), state.parameter_uniforms())
+
+    shard_bytes = ctx.shard_bytes()
+    nbuf = 2
+    if world > 1:
+        shards = [torch.empty(shard_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        gathered = [torch.empty(shard_bytes * world, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    frame = torch.empty(W * H * 4, dtype=torch.uint8, device=dev)
+    ctx.bind_output(shards[0].data_ptr() if world > 1 else None, frame.data_ptr())
+
+    pending = [None] * nbuf
+
+    def one_frame(i):
+        if world == 1:
+            ctx.compute_pass()
+            return
+        b = i % nbuf
+        if pending[b] is not None:          # buffer b's previous gather + assemble must be done
+            pending[b].wait()
+            if rank == 0:
+                ctx.assemble(gathered[b].data_ptr())
+            pending[b] = None
+        ctx.bind_output(shards[b].data_ptr(), frame.data_ptr())
+        ctx.compute_pass()
+        pending[b] = dist.all_gather_into_tensor(gathered[b], shards[b], async_op=True)
+
+    def drain():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                pending[b].wait()
+                if rank == 0:
+                    ctx.assemble(gathered[b].data_ptr())
+                pending[b] = None
+
+    for i in range(args.warmup):
+        one_frame(i)
+    drain()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_frame(i)
+    drain()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- roofline of the dominant kernel: HIP events on the kernel's stream, algorithmic bytes from the
+    # instrumented launch (reference fetch counts) -------------------------------------------------------
+    n_ev = min(max(args.steps, 10), 200)
+    ms = ctx.time_passes(n_ev)
+    ctx.sync()
+    kernel_ms = float(np.mean(ms))
+    st = ctx.stats_pass()
+    counts = torch.tensor([st["n_vol"], st["n_imp"], st["n_rays"]], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts)
+    n_vol, n_imp, n_rays = (int(x) for x in counts.tolist())
+    b_vol = 8 if args.linear else 1
+    local_bytes = st["n_vol"] * b_vol + st["n_imp"] + 4 * st["n_rays"]      # this rank's launch
+    frame_bytes = n_vol * b_vol + n_imp + 4 * W * H                           # whole frame (B_alg)
+    achieved = local_bytes / (kernel_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        rays = W * H
+        out = {
+            "metric": "Mrays/s + achieved HBM GB/s, 256^3 uint8 @ 1920x1080",
+            "value": rays * args.steps / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u8 voxels, f32 compositing",
+            "data": "synthetic (volym_amd.synth.synth_bonsai(%d), seed 20250310)" % args.volume,
+            "config": {
+                "workload": "bonsai %d^3 uint8 @ %dx%d, %s filter, step %g, thr 0.15, opacity on%s, kernel=%s (BASELINE configs[%d])"
+                            % (args.volume, W, H, "linear" if args.linear else "nearest (reference parity)", args.step,
+                               ", importance look-ahead %s" % ("cone" if args.cone else "straight") if args.importance else "",
+                               "macro-cell" if args.kernel == 1 else "direct", 2 if args.kernel == 1 else 1),
+                "viewport": [W, H], "volume": list(dims), "tile_sharding": "interleaved 16x16 tiles, k %% %d" % world,
+            },
+            "achieved_gbs": frame_bytes * args.steps / dt / 1e9,
+            "b_alg_bytes_per_frame": frame_bytes,
+            "b_alg_bytes_per_ray": frame_bytes / rays,
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "volym_raymarch_kernel<%d,false>" % args.kernel,
+                "kernel_avg_ms": kernel_ms, "launch_algorithmic_bytes": local_bytes,
+                "note": "algorithmic bytes = reference fetch count (n_vol*%d + n_imp) + 4 B/pixel; the 32 MiB working set is "
+                        "Infinity-Cache resident, so HBM traffic << algorithmic bytes (DESIGN.md)" % b_vol,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb, _ = cpu_baseline(args, dims, volume, importances, lut, state)
+            out["cpu_baseline"] = cb
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/*
+ * volym_hip.h -- C ABI of the MI355X-native ray-march path (libvolym_hip.so).
+ *
+ * This is the drop-in boundary for the reference's compute plugin:
+ *
+ *     trait ComputeDemo { fn init(ctx, state, output_texture) -> Result<Self>;
+ *                         fn update_gpu_state(&self, ctx, state) -> Result<()>;
+ *                         fn compute_pass(&self, ctx) -> Result<()>; }
+ *                                              -- /root/reference/src/demos/mod.rs:9-17
+ *
+ * and for the wgpu resource wrappers it owns (src/gpu_resources/, src/gpu_context.rs,
+ * src/demos/pipeline.rs).  Plain C, no C++/torch types, no exceptions: a Rust
+ * `extern "C"` block binds it unchanged (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative VOLYM_E_* code; the text of
+ *     the last failure is volym_last_error(ctx) (volym_last_error(NULL) for create).
+ *   - a context is bound to one device and is NOT thread-safe (the reference calls
+ *     everything from the winit event-loop thread, src/event_loop.rs:62).
+ *   - volym_set_* copy from caller memory; the caller may free immediately (as
+ *     queue.write_texture does, src/gpu_resources/volume.rs:81-90).
+ *   - volym_compute_pass only enqueues (src/demos/pipeline.rs:97 queue.submit);
+ *     volym_sync / volym_read_* block.
+ */
+#ifndef VOLYM_HIP_H
+#define VOLYM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOLYM_ABI_VERSION 1
+
+enum {
+    VOLYM_OK = 0,
+    VOLYM_E_INVALID = -1,   /* bad argument / call order */
+    VOLYM_E_HIP = -2,       /* a HIP runtime call failed */
+    VOLYM_E_NO_DEVICE = -3, /* no usable gfx950 device */
+    VOLYM_E_NOMEM = -4,
+    VOLYM_E_STATE = -5      /* volume / importances / transfer function not all set */
+};
+
+/* Volume sampler.  NEAREST is what the reference runs (SamplerDescriptor::default(),
+ * src/gpu_resources/volume.rs:92-95); LINEAR is the trilinear mode BASELINE.json names. */
+enum { VOLYM_FILTER_NEAREST = 0, VOLYM_FILTER_LINEAR = 1 };
+
+/* volym_set_option keys */
+enum {
+    VOLYM_OPT_KERNEL = 1,     /* 0 = direct march (every reference fetch issued),
+                                 1 = macro-cell march (default): empty-space fetches elided,
+                                     step arithmetic replayed exactly                     */
+    VOLYM_OPT_WRITE_F32 = 2,  /* 1 = also store pre-quantisation float RGBA (parity tests) */
+    VOLYM_OPT_MACRO_CELLS = 3 /* macro cells per axis (power of two, 4..64; default 32)    */
+};
+
+/* CameraUniforms, byte-for-byte (src/gpu_resources/camera.rs:56-64; WGSL mirror
+ * shaders/importance_driven_volume_rendering.wgsl:2-7).  Column-major m[col][row]. */
+typedef struct volym_camera_uniforms {
+    float view_matrix[4][4];
+    float projection_matrix[4][4];
+    float inverse_view_proj[4][4];
+    float camera_position[3];
+    float _padding;
+} volym_camera_uniforms;
+
+/* ParameterUniforms, byte-for-byte (src/gpu_resources/parameters.rs:55-66; WGSL mirror
+ * shaders/importance_driven_volume_rendering.wgsl:9-18). */
+typedef struct volym_parameter_uniforms {
+    float density_threshold;
+    uint32_t use_cone_importance_check;
+    uint32_t use_importance_coloring;
+    uint32_t use_opacity;
+    uint32_t use_importance_rendering;
+    uint32_t use_gaussian_smoothing;
+    uint32_t importance_check_ahead_steps;
+    float raymarching_step_size;
+} volym_parameter_uniforms;
+
+/* Reference texture fetches of the current frame, counted by an instrumented
+ * (untimed) launch: B_alg = n_vol*b_vol + n_imp + 4*W*H  (SURVEY.md section 8d). */
+typedef struct volym_stats {
+    uint64_t n_vol;    /* density fetches the reference shader executes   */
+    uint64_t n_imp;    /* importance fetches the reference shader executes */
+    uint64_t n_steps;  /* march-loop iterations                             */
+    uint64_t n_dense;  /* iterations with rho >= density_threshold          */
+    uint64_t n_hit;    /* rays that hit the unit cube                       */
+    uint64_t n_rays;   /* pixels owned by this context (all of them count)  */
+} volym_stats;
+
+typedef struct volym_ctx volym_ctx;
+
+/* --- lifetime: GpuContext::new + GpuWriteTexture2D::new (src/gpu_context.rs:20-62,
+ * src/gpu_resources/texture.rs:40-59).  device_id < 0 = current device. */
+int volym_create(volym_ctx** out, uint32_t width, uint32_t height, int device_id);
+void volym_destroy(volym_ctx* ctx);
+const char* volym_last_error(const volym_ctx* ctx);
+int volym_abi_version(void);
+
+/* Use the caller's HIP stream (hipStream_t as void*; NULL = the context's own). */
+int volym_set_stream(volym_ctx* ctx, void* hip_stream);
+int volym_set_option(volym_ctx* ctx, int key, int value);
+
+/* Screen-tile sharding: this context renders the 16x16 tiles
+ * k with k % world == rank into a compact buffer of volym_local_tiles() tiles. */
+int volym_set_shard(volym_ctx* ctx, uint32_t rank, uint32_t world);
+
+/* --- resources: Simple::init (src/demos/simple/mod.rs:36-110) --------------------- */
+/* GpuVolume::init upload (src/gpu_resources/volume.rs:63-95): nx*ny*nz bytes, x fastest,
+ * already padded/flipped by the host shim (volym_host.h volym_prepare_volume). */
+int volym_set_volume(volym_ctx* ctx, const uint8_t* voxels, uint32_t nx, uint32_t ny,
+                     uint32_t nz, int filter);
+/* GpuImportances::init upload (src/demos/simple/importance.rs:93-131); same dims. */
+int volym_set_importances(volym_ctx* ctx, const uint8_t* importances, uint32_t nx,
+                          uint32_t ny, uint32_t nz);
+/* GPUTransferFunction::new_texture_1d_rgbt upload (src/gpu_resources/transfer_function.rs:36-90):
+ * n RGBA8 texels (the reference uses n = 256), Linear/ClampToEdge sampler. */
+int volym_set_transfer_function(volym_ctx* ctx, const uint8_t* rgba8, uint32_t n);
+
+/* --- per frame ------------------------------------------------------------------ */
+/* ComputeDemo::update_gpu_state (src/demos/pipeline.rs:208-212): GpuCamera::update +
+ * GpuParameters::update.  Fails with VOLYM_E_INVALID on out-of-range parameters. */
+int volym_update(volym_ctx* ctx, const volym_camera_uniforms* camera,
+                 const volym_parameter_uniforms* parameters);
+/* ComputeDemo::compute_pass (src/demos/pipeline.rs:62-102, :214-225): enqueue one
+ * ray-march of every owned tile on the context's stream; returns immediately. */
+int volym_compute_pass(volym_ctx* ctx);
+int volym_sync(volym_ctx* ctx);
+
+/* --- output --------------------------------------------------------------------- */
+/* Full-frame readback (world == 1, or after volym_assemble on the root):
+ * W*H*4 bytes as the rgba8unorm store leaves them / W*H*4 floats before quantisation
+ * (the latter needs VOLYM_OPT_WRITE_F32 = 1). */
+int volym_read_rgba8(volym_ctx* ctx, uint8_t* out);
+int volym_read_rgba32f(volym_ctx* ctx, float* out);
+
+/* Sharded output.  Local buffer = volym_local_tiles() tiles of 16x16 RGBA8 pixels
+ * (1024 bytes each, padded to volym_shard_bytes()); device pointer for the collective. */
+uint32_t volym_local_tiles(const volym_ctx* ctx);
+size_t volym_shard_bytes(const volym_ctx* ctx);
+void* volym_shard_device_ptr(volym_ctx* ctx);
+void* volym_frame_device_ptr(volym_ctx* ctx);
+/* Let the caller own the device buffers (e.g. torch tensors handed to RCCL):
+ * shard_rgba8 = volym_shard_bytes() bytes, frame_rgba8 = W*H*4 bytes; NULL keeps ours. */
+int volym_bind_output(volym_ctx* ctx, void* shard_rgba8, void* frame_rgba8);
+/* Root side of the image gather: `gathered` = world shards back to back in rank order
+ * (device memory, world * volym_shard_bytes() bytes) -> raster W*H*4 in the frame buffer. */
+int volym_assemble(volym_ctx* ctx, const void* gathered);
+/* Host-memory conveniences for callers without a device-side collective (tests, the CLI):
+ * copy this context's shard out (volym_shard_bytes() bytes, padding zeroed) / assemble from
+ * world shards held in host memory. */
+int volym_read_shard(volym_ctx* ctx, uint8_t* out);
+int volym_assemble_host(volym_ctx* ctx, const uint8_t* gathered_host);
+
+/* --- measurement ------------------------------------------------------------------ */
+int volym_stats_pass(volym_ctx* ctx, volym_stats* out);
+/* n back-to-back compute passes timed with HIP events on the context's stream;
+ * ms_each[n] receives each pass's duration (kernel only, inputs resident). */
+int volym_time_passes(volym_ctx* ctx, uint32_t n, float* ms_each);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

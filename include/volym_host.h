@@ -1,0 +1,124 @@
+/*
+ * volym_host.h -- C ABI of the host scene model kept from the reference
+ * (camera / state / transfer_function / asset preparation), exported by the same
+ * libvolym_hip.so.  None of these functions touches the GPU.
+ *
+ * Citations are file:line under /root/reference/.
+ */
+#ifndef VOLYM_HOST_H
+#define VOLYM_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "volym_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/camera.rs:5-19 */
+typedef struct volym_camera {
+    float position[3];
+    float target[3];
+    float up[3];
+    float aspect;
+    float fovy;
+    float znear;
+    float zfar;
+    float horizontal_angle;
+    float vertical_angle;
+    float distance;
+    float max_distance;
+    float min_distance;
+} volym_camera;
+
+/* src/camera.rs:76-83 */
+typedef struct volym_camera_controller {
+    float rotate_horizontal;
+    float rotate_vertical;
+    float scroll;
+    float sensitivity;
+    float zoom_sensitivity;
+} volym_camera_controller;
+
+/* src/state.rs:28-39 (the `density_trheshold` spelling is the reference's) */
+typedef struct volym_state_parameters {
+    float camera_position[3];
+    float density_trheshold;
+    uint32_t use_cone_importance_check;
+    uint32_t use_importance_coloring;
+    uint32_t use_opacity;
+    uint32_t use_importance_rendering;
+    uint32_t use_gaussian_smoothing;
+    uint32_t importance_check_ahead_steps;
+    float raymarching_step_size;
+} volym_state_parameters;
+
+/* src/state.rs:11-26, the parameter half (input/mouse fields are windowing, out of scope) */
+typedef struct volym_state {
+    volym_camera camera;
+    volym_camera_controller camera_controller;
+    float density_threshold;
+    uint32_t use_importance_coloring;
+    uint32_t use_cone_importance_check;
+    uint32_t use_opacity;
+    uint32_t use_importance_rendering;
+    uint32_t use_gaussian_smoothing;
+    uint32_t importance_check_ahead_steps;
+    float raymarching_step_size;
+} volym_state;
+
+/* Camera::default_with_aspect_and_pos (src/camera.rs:22-45) */
+void volym_camera_default_with_aspect_and_pos(volym_camera* c, float aspect,
+                                              const float position[3]);
+/* Camera::orbit (src/camera.rs:47-61) */
+void volym_camera_orbit(volym_camera* c, float horizontal_delta, float vertical_delta,
+                        float zoom_delta);
+/* Camera::view_matrix / projection_matrix (src/camera.rs:63-73), column-major */
+void volym_camera_view_matrix(const volym_camera* c, float out[4][4]);
+void volym_camera_projection_matrix(const volym_camera* c, float out[4][4]);
+/* CameraUniforms::try_from(&Camera) (src/gpu_resources/camera.rs:66-85);
+ * VOLYM_E_INVALID when a matrix cannot be inverted ("inverse_view_proj inversion failed"). */
+int volym_camera_uniforms_from(const volym_camera* c, volym_camera_uniforms* out);
+
+/* CameraController::{new, process_mouse, process_scroll, update_camera} (src/camera.rs:85-117) */
+void volym_camera_controller_new(volym_camera_controller* cc, float sensitivity,
+                                 float zoom_sensitivity);
+void volym_camera_controller_process_mouse(volym_camera_controller* cc, double mouse_dx,
+                                           double mouse_dy);
+void volym_camera_controller_process_scroll(volym_camera_controller* cc, float line_delta);
+void volym_camera_controller_update_camera(volym_camera_controller* cc, volym_camera* camera);
+
+/* StateParameters::default (src/state.rs:41-55) and the benchmark set (src/main.rs:180-190) */
+void volym_state_parameters_default(volym_state_parameters* p);
+void volym_state_parameters_benchmark(volym_state_parameters* p);
+/* State::with_parameters (src/state.rs:58-76), State::update (src/state.rs:153-155) */
+void volym_state_with_parameters(volym_state* s, float aspect, const volym_state_parameters* p);
+void volym_state_update(volym_state* s);
+/* ParameterUniforms::try_from(&State) (src/gpu_resources/parameters.rs:68-83) */
+int volym_parameter_uniforms_from(const volym_state* s, volym_parameter_uniforms* out);
+
+/* TransferFunction::default() baked as GPUTransferFunction does
+ * (src/transfer_function.rs:19-56 + src/gpu_resources/transfer_function.rs:58-69) */
+void volym_transfer_function_default_lut(uint8_t lut_rgba8[1024]);
+/* TransferFunction::{new(255), add_rgb_control_point.., add_alpha_control_point.., build_linear}
+ * then the same bake.  rgb_points: n_rgb x (iso, r, g, b); alpha_points: n_alpha x (iso, a);
+ * points are sorted by iso as the reference does on insertion. */
+int volym_transfer_function_bake(const float* rgb_points, uint32_t n_rgb,
+                                 const float* alpha_points, uint32_t n_alpha,
+                                 uint8_t lut_rgba8[1024]);
+
+/* GpuVolume::init data path (src/gpu_resources/volume.rs:38-61) generalised from the
+ * hard-coded 256^3: zero-pad at the end / truncate to nx*ny*nz, then FlipMode::Y
+ * (src/gpu_resources/mod.rs:70-82) when flip_y != 0. */
+int volym_prepare_volume(const uint8_t* raw, size_t len, uint32_t nx, uint32_t ny, uint32_t nz,
+                         int flip_y, uint8_t* out);
+/* map_segments_to_importance (src/demos/simple/importance.rs:148-158), in place. */
+int volym_map_segments_to_importance(uint8_t* data, size_t len, const uint8_t* label_values,
+                                     const uint8_t* importances, uint32_t n_segments);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,283 @@
+"""Parity of the HIP ray-march (through the C ABI) against the CPU oracle.
+
+Bar (BASELINE.json north_star): |RGBA_f32 - oracle| <= 1e-4 per channel on EVERY pixel;
+the rgba8 image may differ by at most 1 LSB (quantisation of a <=1e-4 float difference);
+the reference-fetch counters -- integer work, one per control-flow decision -- must be
+IDENTICAL, which pins every discrete decision (voxel index, threshold, look-ahead, exit).
+Parity itself is unpinned against the reference (it holds no vectors; oracle/volym_oracle.h).
+"""
+import numpy as np
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # per-channel float tolerance stated by BASELINE.json
+
+
+def _ctx(W, H):
+    from volym_amd import _lib, demo
+    ctx = demo.GpuContext(W, H, 0)
+    ctx.set_option(_lib.OPT_WRITE_F32, 1)
+    return ctx
+
+
+def _render_gpu(ctx, cam, par, variant):
+    from volym_amd import _lib
+    ctx.set_option(_lib.OPT_KERNEL, variant)
+    cu = _lib.CameraUniforms.from_buffer_copy(bytes(cam))
+    pu = _lib.ParameterUniforms.from_buffer_copy(bytes(par))
+    ctx.update(cu, pu)
+    ctx.compute_pass()
+    ctx.sync()
+    return ctx.read_rgba32f(), ctx.read_rgba8(), ctx.stats_pass()
+
+
+def _check(got, ref, label):
+    gf, gu, gk = got
+    rf, ru, rk = ref
+    err, over, du8, frac = common.compare_images(gf, gu, rf, ru, TOL)
+    for k in ("n_vol", "n_imp", "n_steps", "n_dense", "n_hit"):
+        assert gk[k] == rk[k], "%s: counter %s: hip %d oracle %d" % (label, k, gk[k], rk[k])
+    assert over == 0 and err <= TOL, "%s: max err %.3g, %d pixels over %.0e" % (label, err, over, TOL)
+    assert du8 <= 1, "%s: rgba8 differs by %d" % (label, du8)
+    return err, frac
+
+
+@pytest.fixture(scope="module")
+def bonsai64(oracle):
+    raw, labels = common.bonsai(64)
+    dims = (64, 64, 64)
+    vol, imp = common.oracle_scene(oracle, raw, labels, common.BONSAI_SEGMENTS, dims)
+    return raw, labels, dims, vol, imp
+
+
+def _setup_ctx(ctx, raw, labels, segments, dims, filt):
+    from volym_amd import scene
+    ctx.set_volume(scene.prepare_volume(raw, dims, True), dims, filt)
+    ctx.set_importances(scene.prepare_volume(scene.map_segments_to_importance(labels, segments), dims, True), dims)
+    ctx.set_transfer_function(scene.default_lut())
+
+
+@pytest.mark.parametrize("filt", [0, 1], ids=["nearest", "linear"])
+def test_all_flag_combinations_64(oracle, volym_lib, bonsai64, filt):
+    """All 2^5 parameter-flag combinations, both kernel variants, reference-parity camera."""
+    raw, labels, dims, vol, imp = bonsai64
+    W, H = 96, 64
+    cam = oracle.benchmark_camera_uniforms(W / H)
+    lut = oracle.tf_default_lut()
+    worst = 0.0
+    with _ctx(W, H) as ctx:
+        _setup_ctx(ctx, raw, labels, common.BONSAI_SEGMENTS, dims, filt)
+        for flags in common.all_flag_combos():
+            par = oracle.make_parameters(density_threshold=0.15, importance_check_ahead_steps=6,
+                                         raymarching_step_size=0.01, **flags)
+            ref = oracle.render(vol, imp, dims, lut, cam, par, W, H, filter=filt)
+            for variant in (0, 1):
+                err, _ = _check(_render_gpu(ctx, cam, par, variant), ref,
+                                "flags %s variant %d filter %d" % (common.flag_id(flags), variant, filt))
+                worst = max(worst, err)
+    print("worst float error over 32 combos x 2 variants: %.3g" % worst)
+
+
+@pytest.mark.parametrize("pose", [(0.0, 0.0, 0.0), (35.0, 20.0, 0.5), (-120.0, -60.0, 2.0), (90.0, 89.0, 9.0)],
+                         ids=["bench", "orbit1", "orbit2", "pole"])
+def test_orbit_poses(oracle, volym_lib, bonsai64, pose):
+    """Camera poses reachable through Camera::orbit (src/camera.rs:47-61)."""
+    raw, labels, dims, vol, imp = bonsai64
+    W, H = 80, 60
+    cam = oracle.benchmark_camera_uniforms(W / H, *pose)
+    lut = oracle.tf_default_lut()
+    with _ctx(W, H) as ctx:
+        _setup_ctx(ctx, raw, labels, common.BONSAI_SEGMENTS, dims, 0)
+        for kw in (dict(), dict(use_importance_rendering=1), dict(use_importance_rendering=1, use_cone_importance_check=1),
+                   dict(use_gaussian_smoothing=1, density_threshold=0.12)):
+            par = oracle.make_parameters(**kw)
+            ref = oracle.render(vol, imp, dims, lut, cam, par, W, H)
+            for variant in (0, 1):
+                _check(_render_gpu(ctx, cam, par, variant), ref, "pose %s %s v%d" % (pose, kw, variant))
+
+
+@pytest.mark.parametrize("step", [0.003, 0.005, 0.01, 0.02])
+def test_benchmark_step_sweep(oracle, volym_lib, bonsai64, step):
+    """The four step sizes of the reference's sweep (src/main.rs:192)."""
+    raw, labels, dims, vol, imp = bonsai64
+    W, H = 128, 96   # 4:3 like the reference's 1024x768 benchmark window
+    cam = oracle.benchmark_camera_uniforms(W / H)
+    lut = oracle.tf_default_lut()
+    with _ctx(W, H) as ctx:
+        _setup_ctx(ctx, raw, labels, common.BONSAI_SEGMENTS, dims, 0)
+        for kw in (dict(), dict(use_importance_rendering=1, importance_check_ahead_steps=10),
+                   dict(use_importance_rendering=1, use_cone_importance_check=1, importance_check_ahead_steps=10)):
+            par = oracle.make_parameters(raymarching_step_size=step, **kw)
+            ref = oracle.render(vol, imp, dims, lut, cam, par, W, H)
+            for variant in (0, 1):
+                _check(_render_gpu(ctx, cam, par, variant), ref, "step %g %s v%d" % (step, kw, variant))
+
+
+def test_teapot_config1(oracle, volym_lib):
+    """BASELINE config 1: teapot 256x256x178 padded to 256^3, 512x512 (rows sampled for the oracle)."""
+    raw, labels = common.teapot()
+    dims = (256, 256, 256)
+    from volym_amd import synth
+    vol, imp = common.oracle_scene(oracle, raw, labels, synth.TEAPOT_SEGMENTS, dims)
+    W = H = 512
+    cam = oracle.benchmark_camera_uniforms(1.0)
+    lut = oracle.tf_default_lut()
+    with _ctx(W, H) as ctx:
+        _setup_ctx(ctx, raw, labels, synth.TEAPOT_SEGMENTS, dims, 0)
+        for kw in (dict(), dict(use_importance_rendering=1)):
+            par = oracle.make_parameters(**kw)
+            ref = oracle.render(vol, imp, dims, lut, cam, par, W, H)
+            for variant in (0, 1):
+                _check(_render_gpu(ctx, cam, par, variant), ref, "teapot %s v%d" % (kw, variant))
+
+
+def test_ragged_viewport_and_tiny_volume(oracle, volym_lib):
+    """Viewport not a multiple of 16 (guard wgsl:217-219), 1-voxel-thin and non-cubic volumes."""
+    rng = np.random.default_rng(7)
+    for dims in ((1, 1, 1), (5, 3, 2), (17, 33, 9)):
+        n = dims[0] * dims[1] * dims[2]
+        vol = rng.integers(0, 256, n, dtype=np.uint8)
+        imp = np.where(rng.integers(0, 4, n) == 0, 255, 0).astype(np.uint8)
+        for (W, H) in ((1, 1), (37, 23), (50, 17)):
+            cam = oracle.benchmark_camera_uniforms(W / H, 20.0, 10.0, 0.0)
+            lut = oracle.tf_default_lut()
+            with _ctx(W, H) as ctx:
+                ctx.set_volume(vol, dims, 0)
+                ctx.set_importances(imp, dims)
+                ctx.set_transfer_function(lut)
+                for kw in (dict(), dict(use_importance_rendering=1, importance_check_ahead_steps=4), dict(use_opacity=0)):
+                    par = oracle.make_parameters(raymarching_step_size=0.02, **kw)
+                    ref = oracle.render(vol, imp, dims, lut, cam, par, W, H)
+                    for variant in (0, 1):
+                        _check(_render_gpu(ctx, cam, par, variant), ref, "dims %s %dx%d %s v%d" % (dims, W, H, kw, variant))
+
+
+def test_empty_and_saturated_volumes(oracle, volym_lib):
+    """All-zero volume (every hit ray stores alpha 0, misses alpha 1) and all-255 volume."""
+    dims = (32, 32, 32)
+    W, H = 64, 36
+    cam = oracle.benchmark_camera_uniforms(W / H)
+    lut = oracle.tf_default_lut()
+    for value in (0, 255):
+        vol = np.full(32 ** 3, value, np.uint8)
+        imp = np.zeros(32 ** 3, np.uint8)
+        with _ctx(W, H) as ctx:
+            ctx.set_volume(vol, dims, 0)
+            ctx.set_importances(imp, dims)
+            ctx.set_transfer_function(lut)
+            par = oracle.make_parameters()
+            ref = oracle.render(vol, imp, dims, lut, cam, par, W, H)
+            for variant in (0, 1):
+                got = _render_gpu(ctx, cam, par, variant)
+                _check(got, ref, "constant %d v%d" % (value, variant))
+                if value == 0:
+                    a = got[1][..., 3]
+                    assert set(np.unique(a)) <= {0, 255}
+
+
+def test_full_size_properties(oracle, volym_lib):
+    """BASELINE config 2/3 size (bonsai 256^3 @ 1920x1080): size-independent properties.
+    (a) the macro-cell kernel reproduces the direct kernel bit for bit (floats and bytes) and
+        both count the same reference fetches;
+    (b) N virtual ranks' shards assemble to the single-context frame for N = 2, 3, 8;
+    (c) 135 sampled rows agree with the oracle."""
+    from volym_amd import _lib, demo, scene
+    raw, labels = common.bonsai(256)
+    dims = (256, 256, 256)
+    W, H = 1920, 1080
+    cam = oracle.benchmark_camera_uniforms(W / H)
+    par = oracle.make_parameters()
+    cu = _lib.CameraUniforms.from_buffer_copy(bytes(cam))
+    pu = _lib.ParameterUniforms.from_buffer_copy(bytes(par))
+    volume = scene.prepare_volume(raw, dims, True)
+    importances = scene.prepare_volume(scene.map_segments_to_importance(labels, common.BONSAI_SEGMENTS), dims, True)
+    lut = scene.default_lut()
+    with _ctx(W, H) as ctx:
+        ctx.set_volume(volume, dims, 0)
+        ctx.set_importances(importances, dims)
+        ctx.set_transfer_function(lut)
+        f0, u0, k0 = _render_gpu(ctx, cam, par, 0)
+        f1, u1, k1 = _render_gpu(ctx, cam, par, 1)
+        assert np.array_equal(u0, u1) and np.array_equal(f0.view(np.uint32), f1.view(np.uint32))
+        assert k0 == k1
+        # (c) oracle on every 8th row
+        vol_o, imp_o = common.oracle_scene(oracle, raw, labels, common.BONSAI_SEGMENTS, dims)
+        for y0 in range(0, H, 8):
+            rf, ru, _ = oracle.render(vol_o, imp_o, dims, oracle.tf_default_lut(), cam, par, W, H, rows=(y0, y0 + 1))
+            err, over, du8, _ = common.compare_images(f1[y0:y0 + 1], u1[y0:y0 + 1], rf[y0:y0 + 1], ru[y0:y0 + 1], TOL)
+            assert over == 0 and du8 <= 1, (y0, err, over, du8)
+        # (b) virtual ranks on the one device
+        for world in (2, 3, 8):
+            shards = []
+            for rank in range(world):
+                with demo.GpuContext(W, H, 0) as c:
+                    c.set_shard(rank, world)
+                    c.set_volume(volume, dims, 0)
+                    c.set_importances(importances, dims)
+                    c.set_transfer_function(lut)
+                    c.update(cu, pu)
+                    c.compute_pass()
+                    c.sync()
+                    shards.append(c.read_shard())
+            with demo.GpuContext(W, H, 0) as root:      # the root rank's context (rank 0 of `world`)
+                root.set_shard(0, world)
+                root.assemble_host(np.concatenate(shards))
+                root.sync()
+                assert np.array_equal(root.read_rgba8(), u1), "world %d" % world
+
+
+def test_python_demo_mirror_matches_direct_calls(oracle, volym_lib):
+    """Simple::init / update_gpu_state / compute_pass through the host shim == oracle on the
+    uniforms the shim produced (orbit + State -> uniforms -> render)."""
+    from volym_amd import demo, scene, _lib
+    raw, labels = common.bonsai(64)
+    dims = (64, 64, 64)
+    W, H = 64, 48
+    params = scene.StateParameters.benchmark().replace(raymarching_step_size=0.01, use_importance_rendering=1)
+    state = scene.State.with_parameters(W / H, params)
+    state.process_mouse(-100.0, 40.0)   # CameraController::process_mouse -> orbit by (20, -8) degrees
+    state.update()
+    with demo.GpuContext(W, H, 0) as ctx:
+        ctx.set_option(_lib.OPT_WRITE_F32, 1)
+        d = demo.Simple.init(ctx, state, volume_raw=raw, labels_raw=labels, segments=common.BONSAI_SEGMENTS, dims=dims)
+        d.update_gpu_state(ctx, state)
+        d.compute_pass(ctx)
+        ctx.sync()
+        got = (ctx.read_rgba32f(), ctx.read_rgba8(), ctx.stats_pass())
+    vol, imp = common.oracle_scene(oracle, raw, labels, common.BONSAI_SEGMENTS, dims)
+    cam = oracle.CameraUniforms.from_buffer_copy(bytes(state.camera_uniforms()))
+    par = oracle.Parameters.from_buffer_copy(bytes(state.parameter_uniforms()))
+    ref = oracle.render(vol, imp, dims, oracle.tf_default_lut(), cam, par, W, H)
+    _check(got, ref, "demo mirror")
+
+
+def test_error_behaviour(volym_lib):
+    """Error codes instead of aborts (SURVEY.md section 8b 'Errors')."""
+    from volym_amd import _lib, demo
+    with demo.GpuContext(32, 32, 0) as ctx:
+        with pytest.raises(_lib.VolymError) as e:
+            ctx.compute_pass()
+        assert e.value.code == _lib.E_STATE
+        with pytest.raises(_lib.VolymError) as e:
+            ctx.update(_lib.CameraUniforms(), _lib.ParameterUniforms())
+        assert e.value.code == _lib.E_STATE
+        with pytest.raises(_lib.VolymError) as e:
+            ctx.set_option(_lib.OPT_MACRO_CELLS, 33)
+        assert e.value.code == _lib.E_INVALID
+        with pytest.raises(_lib.VolymError) as e:
+            ctx.set_shard(2, 2)
+        assert e.value.code == _lib.E_INVALID
+        v = np.zeros(8, np.uint8)
+        ctx.set_volume(v, (2, 2, 2))
+        ctx.set_importances(v, (2, 2, 2))
+        ctx.set_transfer_function(np.zeros(1024, np.uint8))
+        bad = _lib.ParameterUniforms(0.15, 0, 0, 1, 0, 0, 15, 0.0)   # step 0 would never terminate
+        with pytest.raises(_lib.VolymError) as e:
+            ctx.update(_lib.CameraUniforms(), bad)
+        assert e.value.code == _lib.E_INVALID
+    with pytest.raises(_lib.VolymError) as e:
+        demo.GpuContext(0, 10, 0)
+    assert e.value.code == _lib.E_INVALID

@@ -1,0 +1,537 @@
+// libvolym_hip.so: context + C ABI (include/volym_hip.h) over the gfx950 kernels.
+// Replaces the reference's gpu_context.rs / gpu_resources/* / demos/pipeline.rs for the
+// ray-march path; citations are file:line under /root/reference/.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/volym_hip.h"
+#include "raymarch_kernels.h"
+
+using namespace volym;
+
+static_assert(sizeof(volym_camera_uniforms) == 208, "CameraUniforms is 208 bytes (src/gpu_resources/camera.rs:56-64)");
+static_assert(sizeof(volym_parameter_uniforms) == 32, "ParameterUniforms is 32 bytes (src/gpu_resources/parameters.rs:55-66)");
+
+// cos/sin of (s/8) * 2 * 3.14159 for s = 0..7 (wgsl:99-103), f32
+static const float k_cone_cos[8] = {0x1p+0f, 0x1.6a09f6p-1f, 0x1.54442ep-20f, -0x1.6a09bap-1f,
+                                    -0x1p+0f, -0x1.6a0a32p-1f, -0x1.fe6644p-19f, 0x1.6a097ep-1f};
+static const float k_cone_sin[8] = {0x0p+0f, 0x1.6a09d8p-1f, 0x1p+0f, 0x1.6a0a14p-1f,
+                                    0x1.54442ep-19f, -0x1.6a099cp-1f, -0x1p+0f, -0x1.6a0a5p-1f};
+
+struct volym_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    uint32_t W = 0, H = 0, tiles_x = 0, tiles_y = 0, n_tiles = 0;
+    uint32_t rank = 0, world = 1, n_local = 0, shard_tiles = 0;
+
+    uint8_t* d_vol = nullptr;
+    uint8_t* d_imp = nullptr;
+    uint32_t nx = 0, ny = 0, nz = 0;
+    uint32_t inx = 0, iny = 0, inz = 0;
+    int filter = VOLYM_FILTER_NEAREST;
+    uint8_t lut[256 * 4] = {};
+    uint32_t tf_n = 0;
+    bool have_vol = false, have_imp = false, have_tf = false, have_frame = false;
+
+    FrameTables* d_tables = nullptr;
+    FrameTables h_tables;
+    bool tables_dirty = true;
+    float tables_alpha_y = -1.0f;
+
+    uint8_t* d_mc = nullptr;
+    uint32_t mc_n = 32, mc_built_n = 0;
+    bool mc_dirty = true;
+
+    uint32_t* d_shard_own = nullptr;
+    uint32_t* d_frame_own = nullptr;
+    uint32_t* d_shard = nullptr;
+    uint32_t* d_frame = nullptr;
+    float4* d_f32 = nullptr;
+    uint8_t* d_gather_tmp = nullptr;
+    size_t gather_tmp_bytes = 0;
+    Counters* d_counters = nullptr;
+
+    FrameParams fp;
+    int kernel_variant = 1;
+    bool write_f32 = false;
+    uint32_t xcd_bands = 0;
+    std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(volym_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, VOLYM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static void recompute_shard(volym_ctx* c)
+{
+    c->n_local = c->n_tiles > c->rank ? (c->n_tiles - c->rank + c->world - 1) / c->world : 0;
+    c->shard_tiles = (c->n_tiles + c->world - 1) / c->world;   // equal-sized shards, padded
+}
+
+extern "C" {
+
+int volym_abi_version(void) { return VOLYM_ABI_VERSION; }
+
+const char* volym_last_error(const volym_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int volym_create(volym_ctx** out, uint32_t width, uint32_t height, int device_id)
+{
+    if (!out) return fail(nullptr, VOLYM_E_INVALID, "volym_create: out is NULL");
+    *out = nullptr;
+    if (width == 0 || height == 0 || width > 32768 || height > 32768)
+        return fail(nullptr, VOLYM_E_INVALID, "volym_create: viewport must be 1..32768 in each dimension");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(nullptr, VOLYM_E_NO_DEVICE, "volym_create: no HIP device visible");
+    int dev = device_id;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= n_dev) return fail(nullptr, VOLYM_E_NO_DEVICE, "volym_create: device_id out of range");
+    hipDeviceProp_t prop;
+    HIPCHK(nullptr, hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, VOLYM_E_NO_DEVICE,
+                    std::string("volym_create: this library carries gfx950 code only, device is ") + prop.gcnArchName);
+    HIPCHK(nullptr, hipSetDevice(dev));
+
+    volym_ctx* c = new (std::nothrow) volym_ctx();
+    if (!c) return fail(nullptr, VOLYM_E_NOMEM, "volym_create: out of host memory");
+    c->device = dev;
+    c->W = width; c->H = height;
+    c->tiles_x = (width + 15u) / 16u;     // src/demos/pipeline.rs:83-87
+    c->tiles_y = (height + 15u) / 16u;
+    c->n_tiles = c->tiles_x * c->tiles_y;
+    recompute_shard(c);
+    std::memset(&c->fp, 0, sizeof c->fp);
+    std::memset(&c->h_tables, 0, sizeof c->h_tables);
+
+    auto bail = [&](hipError_t e, const char* what) {
+        std::string m = std::string(what) + ": " + hipGetErrorString(e);
+        volym_destroy(c);
+        return fail(nullptr, e == hipErrorOutOfMemory ? VOLYM_E_NOMEM : VOLYM_E_HIP, m);
+    };
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    c->stream = c->own_stream;
+    const size_t frame_bytes = static_cast<size_t>(width) * height * 4;
+    if ((e = hipMalloc(&c->d_frame_own, frame_bytes)) != hipSuccess) return bail(e, "hipMalloc(frame)");
+    if ((e = hipMalloc(&c->d_shard_own, static_cast<size_t>(c->n_tiles) * 1024)) != hipSuccess) return bail(e, "hipMalloc(shard)");
+    if ((e = hipMalloc(&c->d_tables, sizeof(FrameTables))) != hipSuccess) return bail(e, "hipMalloc(tables)");
+    if ((e = hipMalloc(&c->d_counters, sizeof(Counters))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMemset(c->d_frame_own, 0, frame_bytes)) != hipSuccess) return bail(e, "hipMemset(frame)");
+    c->d_frame = c->d_frame_own;
+    c->d_shard = c->d_shard_own;
+    *out = c;
+    return VOLYM_OK;
+}
+
+void volym_destroy(volym_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_vol); (void)hipFree(c->d_imp); (void)hipFree(c->d_tables); (void)hipFree(c->d_mc);
+    (void)hipFree(c->d_shard_own); (void)hipFree(c->d_frame_own); (void)hipFree(c->d_f32);
+    (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_counters);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int volym_set_stream(volym_ctx* c, void* hip_stream)
+{
+    if (!c) return VOLYM_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return VOLYM_OK;
+}
+
+int volym_set_option(volym_ctx* c, int key, int value)
+{
+    if (!c) return VOLYM_E_INVALID;
+    switch (key) {
+    case VOLYM_OPT_KERNEL:
+        if (value != 0 && value != 1) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_KERNEL: 0 (direct) or 1 (macro-cell)");
+        c->kernel_variant = value;
+        return VOLYM_OK;
+    case VOLYM_OPT_WRITE_F32:
+        c->write_f32 = value != 0;
+        return VOLYM_OK;
+    case VOLYM_OPT_MACRO_CELLS:
+        if (value < 4 || value > 64 || (value & (value - 1)) != 0)
+            return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_MACRO_CELLS: power of two in 4..64");
+        c->mc_n = static_cast<uint32_t>(value);
+        c->mc_dirty = true;
+        return VOLYM_OK;
+    case 100:   // undocumented tuning knob: block->tile remap bands per XCD (0 = identity)
+        if (value < 0 || value > 64) return fail(c, VOLYM_E_INVALID, "xcd bands: 0..64");
+        c->xcd_bands = static_cast<uint32_t>(value);
+        return VOLYM_OK;
+    default:
+        return fail(c, VOLYM_E_INVALID, "volym_set_option: unknown key");
+    }
+}
+
+int volym_set_shard(volym_ctx* c, uint32_t rank, uint32_t world)
+{
+    if (!c) return VOLYM_E_INVALID;
+    if (world == 0 || rank >= world || world > 4096) return fail(c, VOLYM_E_INVALID, "volym_set_shard: need rank < world <= 4096");
+    c->rank = rank; c->world = world;
+    recompute_shard(c);
+    return VOLYM_OK;
+}
+
+static int upload_volume(volym_ctx* c, uint8_t** dst, const uint8_t* src, uint32_t nx, uint32_t ny, uint32_t nz)
+{
+    if (!src || nx == 0 || ny == 0 || nz == 0) return fail(c, VOLYM_E_INVALID, "volume: NULL data or zero dimension");
+    const uint64_t n = static_cast<uint64_t>(nx) * ny * nz;
+    if (nx > 4096 || ny > 4096 || nz > 4096 || n > 0xffffffffull)
+        return fail(c, VOLYM_E_INVALID, "volume: each dimension <= 4096 and nx*ny*nz < 2^32");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (*dst) { HIPCHK(c, hipFree(*dst)); *dst = nullptr; }
+    hipError_t e = hipMalloc(dst, n);
+    if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(volume): ") + hipGetErrorString(e));
+    HIPCHK(c, hipMemcpy(*dst, src, n, hipMemcpyHostToDevice));
+    return VOLYM_OK;
+}
+
+int volym_set_volume(volym_ctx* c, const uint8_t* voxels, uint32_t nx, uint32_t ny, uint32_t nz, int filter)
+{
+    if (!c) return VOLYM_E_INVALID;
+    if (filter != VOLYM_FILTER_NEAREST && filter != VOLYM_FILTER_LINEAR)
+        return fail(c, VOLYM_E_INVALID, "volym_set_volume: filter must be VOLYM_FILTER_NEAREST or VOLYM_FILTER_LINEAR");
+    int rc = upload_volume(c, &c->d_vol, voxels, nx, ny, nz);
+    if (rc != VOLYM_OK) { c->have_vol = false; return rc; }
+    c->nx = nx; c->ny = ny; c->nz = nz; c->filter = filter;
+    c->have_vol = true;
+    c->mc_dirty = true;
+    return VOLYM_OK;
+}
+
+int volym_set_importances(volym_ctx* c, const uint8_t* importances, uint32_t nx, uint32_t ny, uint32_t nz)
+{
+    if (!c) return VOLYM_E_INVALID;
+    int rc = upload_volume(c, &c->d_imp, importances, nx, ny, nz);
+    if (rc != VOLYM_OK) { c->have_imp = false; return rc; }
+    c->inx = nx; c->iny = ny; c->inz = nz;
+    c->have_imp = true;
+    return VOLYM_OK;
+}
+
+int volym_set_transfer_function(volym_ctx* c, const uint8_t* rgba8, uint32_t n)
+{
+    if (!c) return VOLYM_E_INVALID;
+    if (!rgba8 || n < 1 || n > 256) return fail(c, VOLYM_E_INVALID, "volym_set_transfer_function: 1..256 RGBA8 texels");
+    std::memset(c->lut, 0, sizeof c->lut);
+    std::memcpy(c->lut, rgba8, static_cast<size_t>(n) * 4);
+    c->tf_n = n;
+    c->have_tf = true;
+    c->tables_dirty = true;
+    return VOLYM_OK;
+}
+
+}  // extern "C"
+
+// ---- host-side table construction (EXACT arithmetic, same recipe as the device) --------------
+static void host_texel_linear(float u, int n, int& i0, int& i1, float& w)
+{
+    const float x = u * static_cast<float>(n) - 0.5f;
+    float fl = std::floor(x);
+    w = x - fl;
+    if (!(fl >= -2.0f)) fl = -2.0f;
+    if (fl > static_cast<float>(n)) fl = static_cast<float>(n);
+    const int i = static_cast<int>(fl);
+    i0 = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    i1 = i + 1 < 0 ? 0 : (i + 1 > n - 1 ? n - 1 : i + 1);
+}
+
+static void build_tables(volym_ctx* c, float alpha_y)
+{
+    FrameTables& t = c->h_tables;
+    const int n = static_cast<int>(c->tf_n);
+    for (int b = 0; b < 256; ++b) {
+        t.rho[b] = static_cast<float>(b) / 255.0f;
+        const uint8_t* q = c->lut + 4 * (b < n ? b : n - 1);
+        t.lut_f[b] = make_float4(static_cast<float>(q[0]) / 255.0f, static_cast<float>(q[1]) / 255.0f,
+                                 static_cast<float>(q[2]) / 255.0f, static_cast<float>(q[3]) / 255.0f);
+    }
+    for (int b = 0; b < 256; ++b) {
+        int i0, i1;
+        float w;
+        host_texel_linear(t.rho[b], n, i0, i1, w);   // wgsl:297-302: rho is the coordinate
+        const float4 a = t.lut_f[i0], bb = t.lut_f[i1];
+        const float iw = 1.0f - w;
+        const float A = a.w * iw + bb.w * w;
+        t.tf_tab[b] = make_float4(a.x * iw + bb.x * w, a.y * iw + bb.y * w, a.z * iw + bb.z * w,
+                                  1.0f - wgsl_pow(1.0f - A, alpha_y));   // wgsl:314
+        t.ic_alpha[b] = 1.0f - wgsl_pow(1.0f - t.rho[b], alpha_y);       // wgsl:83-84, :314
+    }
+}
+
+static int ensure_frame_resources(volym_ctx* c)
+{
+    if (c->write_f32 && !c->d_f32) {
+        hipError_t e = hipMalloc(&c->d_f32, static_cast<size_t>(c->W) * c->H * sizeof(float4));
+        if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(f32 frame): ") + hipGetErrorString(e));
+    }
+    if (c->mc_dirty || c->mc_built_n != c->mc_n) {
+        if (c->d_mc) { HIPCHK(c, hipFree(c->d_mc)); c->d_mc = nullptr; }
+        const uint32_t cells = c->mc_n * c->mc_n * c->mc_n;
+        hipError_t e = hipMalloc(&c->d_mc, cells);
+        if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(macro cells): ") + hipGetErrorString(e));
+        hipLaunchKernelGGL(volym_macrocell_kernel, dim3(cells), dim3(256), 0, c->stream, c->d_vol, c->d_mc, c->nx, c->ny, c->nz, c->mc_n);
+        HIPCHK(c, hipGetLastError());
+        c->mc_dirty = false;
+        c->mc_built_n = c->mc_n;
+    }
+    return VOLYM_OK;
+}
+
+extern "C" {
+
+int volym_update(volym_ctx* c, const volym_camera_uniforms* cam, const volym_parameter_uniforms* par)
+{
+    if (!c) return VOLYM_E_INVALID;
+    if (!cam || !par) return fail(c, VOLYM_E_INVALID, "volym_update: NULL uniforms");
+    if (!c->have_vol || !c->have_imp || !c->have_tf)
+        return fail(c, VOLYM_E_STATE, "volym_update: set volume, importances and transfer function first");
+    if (c->nx != c->inx || c->ny != c->iny || c->nz != c->inz)
+        return fail(c, VOLYM_E_STATE, "volym_update: volume and importances differ in size");
+    // The reference loops `while t < exit` with t += step on the GPU; a step that cannot advance t
+    // would never terminate there.  Refuse such inputs instead of hanging the device.
+    const float step = par->raymarching_step_size;
+    if (!(step >= 1.0e-4f && step <= 1.0f)) return fail(c, VOLYM_E_INVALID, "volym_update: raymarching_step_size must be in [1e-4, 1]");
+    if (!std::isfinite(par->density_threshold)) return fail(c, VOLYM_E_INVALID, "volym_update: density_threshold is not finite");
+    if (par->importance_check_ahead_steps > 4096u) return fail(c, VOLYM_E_INVALID, "volym_update: importance_check_ahead_steps > 4096");
+    for (int i = 0; i < 16; ++i)
+        if (!std::isfinite((&cam->inverse_view_proj[0][0])[i])) return fail(c, VOLYM_E_INVALID, "volym_update: inverse_view_proj is not finite");
+    for (int i = 0; i < 3; ++i)
+        if (!(std::fabs(cam->camera_position[i]) <= 64.0f)) return fail(c, VOLYM_E_INVALID, "volym_update: |camera_position| must be <= 64 per axis");
+
+    HIPCHK(c, hipSetDevice(c->device));
+    FrameParams& fp = c->fp;
+    std::memcpy(fp.ivp, cam->inverse_view_proj, sizeof fp.ivp);
+    fp.eye[0] = cam->camera_position[0]; fp.eye[1] = cam->camera_position[1]; fp.eye[2] = cam->camera_position[2];
+    fp.thr = par->density_threshold;
+    fp.base_step = step;
+    fp.min_step = step * 0.25f;          // wgsl:244
+    fp.alpha_y = fp.min_step * 100.0f;   // wgsl:314 with current_step_size == min_step_size
+    fp.flags = (par->use_cone_importance_check == 1u ? F_CONE : 0u) | (par->use_importance_coloring == 1u ? F_IMP_COLORING : 0u) |
+               (par->use_opacity == 1u ? F_OPACITY : 0u) | (par->use_importance_rendering == 1u ? F_IMP_RENDERING : 0u) |
+               (par->use_gaussian_smoothing == 1u ? F_GAUSSIAN : 0u) | (c->filter == VOLYM_FILTER_LINEAR ? F_LINEAR : 0u);
+    fp.ahead_steps = par->importance_check_ahead_steps;
+    fp.W = c->W; fp.H = c->H;
+    fp.nx = c->nx; fp.ny = c->ny; fp.nz = c->nz;
+    fp.tiles_x = c->tiles_x; fp.n_tiles = c->n_tiles;
+    fp.tf_n = c->tf_n;
+    const float sigma = 1.5f;            // wgsl:255
+    for (int i = -2; i <= 2; ++i) {
+        const float x = static_cast<float>(i) * 0.005f;
+        fp.gauss_w[i + 2] = wgsl_exp(-(x * x) / (2.0f * sigma * sigma));
+    }
+    std::memcpy(fp.cone_cos, k_cone_cos, sizeof k_cone_cos);
+    std::memcpy(fp.cone_sin, k_cone_sin, sizeof k_cone_sin);
+
+    if (c->tables_dirty || c->tables_alpha_y != fp.alpha_y) {
+        build_tables(c, fp.alpha_y);
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // the previous frame may still read d_tables
+        HIPCHK(c, hipMemcpy(c->d_tables, &c->h_tables, sizeof(FrameTables), hipMemcpyHostToDevice));
+        c->tables_dirty = false;
+        c->tables_alpha_y = fp.alpha_y;
+    }
+    uint32_t tb = 256;
+    for (int b = 255; b >= 0; --b)
+        if (c->h_tables.rho[b] >= fp.thr) tb = static_cast<uint32_t>(b); else break;
+    fp.thr_byte = tb;
+    c->have_frame = true;
+    return VOLYM_OK;
+}
+
+}  // extern "C"
+
+template <bool COUNT>
+static int launch_march(volym_ctx* c)
+{
+    int rc = ensure_frame_resources(c);
+    if (rc != VOLYM_OK) return rc;
+    FrameParams fp = c->fp;
+    fp.rank = c->rank; fp.world = c->world; fp.n_local = c->n_local;
+    fp.mc_n = c->mc_n;
+    fp.xcd_bands = c->xcd_bands;
+    if (c->world == 1) fp.flags |= F_RASTER;
+    if (c->write_f32 && c->world == 1) fp.flags |= F_WRITE_F32;
+    if (c->n_local == 0) return VOLYM_OK;
+    uint32_t grid = c->n_local;
+    if (fp.xcd_bands) {
+        const uint32_t chunks = 8u * fp.xcd_bands;
+        const uint32_t per_chunk = (c->n_local + chunks - 1u) / chunks;
+        grid = per_chunk * chunks;
+    }
+    Counters* cnt = COUNT ? c->d_counters : nullptr;
+    if (c->kernel_variant == 1)
+        hipLaunchKernelGGL((volym_raymarch_kernel<1, COUNT>), dim3(grid), dim3(256), 0, c->stream, c->d_vol, c->d_imp, c->d_tables,
+                           c->d_mc, c->d_shard, c->d_frame, c->d_f32, cnt, fp);
+    else
+        hipLaunchKernelGGL((volym_raymarch_kernel<0, COUNT>), dim3(grid), dim3(256), 0, c->stream, c->d_vol, c->d_imp, c->d_tables,
+                           c->d_mc, c->d_shard, c->d_frame, c->d_f32, cnt, fp);
+    HIPCHK(c, hipGetLastError());
+    return VOLYM_OK;
+}
+
+extern "C" {
+
+int volym_compute_pass(volym_ctx* c)
+{
+    if (!c) return VOLYM_E_INVALID;
+    if (!c->have_frame) return fail(c, VOLYM_E_STATE, "volym_compute_pass: call volym_update first");
+    HIPCHK(c, hipSetDevice(c->device));
+    return launch_march<false>(c);
+}
+
+int volym_sync(volym_ctx* c)
+{
+    if (!c) return VOLYM_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VOLYM_OK;
+}
+
+int volym_read_rgba8(volym_ctx* c, uint8_t* out)
+{
+    if (!c || !out) return VOLYM_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_frame, static_cast<size_t>(c->W) * c->H * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VOLYM_OK;
+}
+
+int volym_read_rgba32f(volym_ctx* c, float* out)
+{
+    if (!c || !out) return VOLYM_E_INVALID;
+    if (!c->write_f32 || !c->d_f32 || c->world != 1)
+        return fail(c, VOLYM_E_STATE, "volym_read_rgba32f: needs VOLYM_OPT_WRITE_F32 = 1, world == 1 and a rendered frame");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_f32, static_cast<size_t>(c->W) * c->H * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VOLYM_OK;
+}
+
+uint32_t volym_local_tiles(const volym_ctx* c) { return c ? c->n_local : 0u; }
+size_t volym_shard_bytes(const volym_ctx* c) { return c ? static_cast<size_t>(c->shard_tiles) * 1024u : 0u; }
+void* volym_shard_device_ptr(volym_ctx* c) { return c ? c->d_shard : nullptr; }
+void* volym_frame_device_ptr(volym_ctx* c) { return c ? c->d_frame : nullptr; }
+
+int volym_bind_output(volym_ctx* c, void* shard_rgba8, void* frame_rgba8)
+{
+    if (!c) return VOLYM_E_INVALID;
+    // takes effect for launches enqueued after this call; earlier launches keep their pointers
+    c->d_shard = shard_rgba8 ? static_cast<uint32_t*>(shard_rgba8) : c->d_shard_own;
+    c->d_frame = frame_rgba8 ? static_cast<uint32_t*>(frame_rgba8) : c->d_frame_own;
+    return VOLYM_OK;
+}
+
+int volym_read_shard(volym_ctx* c, uint8_t* out)
+{
+    if (!c || !out) return VOLYM_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    // the padding tile of a short shard is never written by the kernel: define it
+    const size_t used = static_cast<size_t>(c->n_local) * 1024u, total = volym_shard_bytes(c);
+    HIPCHK(c, hipMemcpyAsync(out, c->d_shard, used, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (total > used) std::memset(out + used, 0, total - used);
+    return VOLYM_OK;
+}
+
+int volym_assemble(volym_ctx* c, const void* gathered)
+{
+    if (!c || !gathered) return VOLYM_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(volym_assemble_kernel, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint32_t*>(gathered),
+                       c->d_frame, c->W, c->H, c->tiles_x, c->n_tiles, c->world, c->shard_tiles);
+    HIPCHK(c, hipGetLastError());
+    return VOLYM_OK;
+}
+
+int volym_assemble_host(volym_ctx* c, const uint8_t* gathered_host)
+{
+    if (!c || !gathered_host) return VOLYM_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = volym_shard_bytes(c) * c->world;
+    if (c->gather_tmp_bytes < bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_gather_tmp) { HIPCHK(c, hipFree(c->d_gather_tmp)); c->d_gather_tmp = nullptr; c->gather_tmp_bytes = 0; }
+        hipError_t e = hipMalloc(&c->d_gather_tmp, bytes);
+        if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(gather): ") + hipGetErrorString(e));
+        c->gather_tmp_bytes = bytes;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_gather_tmp, gathered_host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return volym_assemble(c, c->d_gather_tmp);
+}
+
+int volym_stats_pass(volym_ctx* c, volym_stats* out)
+{
+    if (!c || !out) return VOLYM_E_INVALID;
+    if (!c->have_frame) return fail(c, VOLYM_E_STATE, "volym_stats_pass: call volym_update first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));
+    int rc = launch_march<true>(c);
+    if (rc != VOLYM_OK) return rc;
+    Counters h;
+    HIPCHK(c, hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out->n_vol = h.n_vol; out->n_imp = h.n_imp; out->n_steps = h.n_steps; out->n_dense = h.n_dense; out->n_hit = h.n_hit;
+    // every pixel of an owned tile that lies inside the frame launches a ray (wgsl:217-219)
+    uint64_t rays = 0;
+    for (uint32_t k = c->rank; k < c->n_tiles; k += c->world) {
+        const uint32_t tx = k % c->tiles_x, ty = k / c->tiles_x;
+        const uint32_t w = std::min(16u, c->W - tx * 16u), h2 = std::min(16u, c->H - ty * 16u);
+        rays += static_cast<uint64_t>(w) * h2;
+    }
+    out->n_rays = rays;
+    return VOLYM_OK;
+}
+
+int volym_time_passes(volym_ctx* c, uint32_t n, float* ms_each)
+{
+    if (!c || !ms_each || n == 0 || n > 100000) return VOLYM_E_INVALID;
+    if (!c->have_frame) return fail(c, VOLYM_E_STATE, "volym_time_passes: call volym_update first");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<hipEvent_t> ev(n + 1, nullptr);
+    int rc = VOLYM_OK;
+    for (uint32_t i = 0; i <= n && rc == VOLYM_OK; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) rc = fail(c, VOLYM_E_HIP, "hipEventCreate failed");
+    if (rc == VOLYM_OK) rc = ensure_frame_resources(c);
+    if (rc == VOLYM_OK) {
+        (void)hipEventRecord(ev[0], c->stream);
+        for (uint32_t i = 0; i < n && rc == VOLYM_OK; ++i) {
+            rc = launch_march<false>(c);
+            if (hipEventRecord(ev[i + 1], c->stream) != hipSuccess && rc == VOLYM_OK) rc = fail(c, VOLYM_E_HIP, "hipEventRecord failed");
+        }
+        if (hipStreamSynchronize(c->stream) != hipSuccess && rc == VOLYM_OK) rc = fail(c, VOLYM_E_HIP, "hipStreamSynchronize failed");
+        if (rc == VOLYM_OK)
+            for (uint32_t i = 0; i < n; ++i)
+                if (hipEventElapsedTime(&ms_each[i], ev[i], ev[i + 1]) != hipSuccess) { rc = fail(c, VOLYM_E_HIP, "hipEventElapsedTime failed"); break; }
+    }
+    for (auto e : ev) if (e) (void)hipEventDestroy(e);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,307 @@
+// Device-side building blocks of the ray-march (gfx950 only).
+//
+// Two kinds of arithmetic live here and must not be mixed up:
+//   EXACT   -- everything that feeds a discrete decision (voxel index, rho >= threshold,
+//              importance tests, the alpha < 0.95 exit, the step state machine).  Plain IEEE
+//              f32 in the order the WGSL states it; the file is compiled with
+//              -ffp-contract=off so no mul+add is fused behind our back.
+//   COLOUR  -- shading that only moves the output continuously (normalisations, Blinn-Phong,
+//              colour accumulation).  Free to use v_rsq_f32 and explicit fma; the error budget
+//              is 1e-4 per channel (BASELINE.json), the observed error ~1e-6.
+//
+// "wgsl" = /root/reference/shaders/importance_driven_volume_rendering.wgsl.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "wgsl_math.h"
+
+namespace volym {
+
+enum : uint32_t {
+    F_CONE = 1u << 0,          // use_cone_importance_check
+    F_IMP_COLORING = 1u << 1,  // use_importance_coloring
+    F_OPACITY = 1u << 2,       // use_opacity
+    F_IMP_RENDERING = 1u << 3, // use_importance_rendering
+    F_GAUSSIAN = 1u << 4,      // use_gaussian_smoothing
+    F_LINEAR = 1u << 5,        // VOLYM_FILTER_LINEAR
+    F_WRITE_F32 = 1u << 6,
+    F_RASTER = 1u << 7,        // world == 1: store straight into the W x H raster
+};
+
+struct FrameParams {
+    float ivp[16];   // inverse_view_proj, column-major
+    float eye[3];
+    float thr;       // density_threshold
+    float base_step; // raymarching_step_size
+    float min_step;  // base_step * 0.25
+    float alpha_y;   // min_step * 100: exponent of the opacity correction (wgsl:314)
+    uint32_t flags;
+    uint32_t ahead_steps;
+    uint32_t W, H;
+    uint32_t nx, ny, nz;
+    uint32_t tiles_x, n_tiles;       // 16x16 tiles of the whole frame
+    uint32_t rank, world, n_local;   // tile k is ours when k % world == rank; local index k / world
+    uint32_t thr_byte;               // smallest b with b/255 >= thr (256 when none)
+    uint32_t tf_n;
+    uint32_t mc_n;                   // macro cells per axis
+    uint32_t xcd_bands;              // block -> tile remap granularity (0 = identity)
+    float gauss_w[5];
+    float cone_cos[8], cone_sin[8];
+};
+
+// Per-(transfer function, parameters) tables, built on the host with the same wgsl_math.h
+// recipe and staged into LDS by every workgroup.
+struct FrameTables {
+    float4 tf_tab[256];   // nearest, unsmoothed: rgb = TF(b/255), w = 1 - pow(1 - A, alpha_y)
+    float4 lut_f[256];    // decoded LUT texels (continuous-rho modes)
+    float ic_alpha[256];  // importance colouring: 1 - pow(1 - i/255, alpha_y)
+    float rho[256];       // b / 255
+};
+
+struct Counters {
+    unsigned long long n_vol, n_imp, n_steps, n_dense, n_hit;
+};
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+// EXACT: (x*x' + y*y') + z*z'
+__device__ __forceinline__ float dot_exact(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b)
+{
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float length_exact(V3 a) { return __builtin_sqrtf(dot_exact(a, a)); }
+// EXACT WGSL normalize: v / length(v) (IEEE sqrt and divisions)
+__device__ __forceinline__ V3 normalize_exact(V3 a) { return a / length_exact(a); }
+// COLOUR: fused dot and hardware reciprocal square root
+__device__ __forceinline__ float dot_fast(V3 a, V3 b)
+{
+    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
+}
+
+struct Grid {
+    const uint8_t* __restrict__ vol;
+    const uint8_t* __restrict__ imp;
+    int nx, ny, nz;
+    float fnx, fny, fnz;      // (float)n
+    float hix, hiy, hiz;      // (float)(n - 1)
+};
+
+// nearest filter + ClampToEdge: i = clamp(floor(u * n), 0, n - 1)  (EXACT)
+__device__ __forceinline__ int texel_nearest(float u, float fn, float hi)
+{
+    float f = __builtin_floorf(u * fn);
+    f = __builtin_fminf(__builtin_fmaxf(f, 0.0f), hi);
+    return static_cast<int>(f);
+}
+
+__device__ __forceinline__ uint32_t voxel_offset(const Grid& g, int ix, int iy, int iz)
+{
+    return static_cast<uint32_t>(ix) +
+           static_cast<uint32_t>(g.nx) * (static_cast<uint32_t>(iy) + static_cast<uint32_t>(g.ny) * static_cast<uint32_t>(iz));
+}
+
+__device__ __forceinline__ uint32_t nearest_offset(const Grid& g, V3 p)
+{
+    return voxel_offset(g, texel_nearest(p.x, g.fnx, g.hix), texel_nearest(p.y, g.fny, g.hiy),
+                        texel_nearest(p.z, g.fnz, g.hiz));
+}
+
+// linear filter + ClampToEdge along one axis: x = u*n - 0.5, i0 = floor(x), w = x - i0  (EXACT)
+__device__ __forceinline__ void texel_linear(float u, float fn, int n, int& i0, int& i1, float& w)
+{
+    const float x = u * fn - 0.5f;
+    float fl = __builtin_floorf(x);
+    w = x - fl;
+    fl = __builtin_fminf(__builtin_fmaxf(fl, -2.0f), fn);
+    const int i = static_cast<int>(fl);
+    i0 = min(max(i, 0), n - 1);
+    i1 = min(max(i + 1, 0), n - 1);
+}
+
+// trilinear density in [0,1]  (EXACT: x, then y, then z; a*(1-w) + b*w)
+__device__ __forceinline__ float fetch_linear(const Grid& g, const float* __restrict__ s_rho, V3 p)
+{
+    int x0, x1, y0, y1, z0, z1;
+    float fx, fy, fz;
+    texel_linear(p.x, g.fnx, g.nx, x0, x1, fx);
+    texel_linear(p.y, g.fny, g.ny, y0, y1, fy);
+    texel_linear(p.z, g.fnz, g.nz, z0, z1, fz);
+    const float t000 = s_rho[g.vol[voxel_offset(g, x0, y0, z0)]];
+    const float t100 = s_rho[g.vol[voxel_offset(g, x1, y0, z0)]];
+    const float t010 = s_rho[g.vol[voxel_offset(g, x0, y1, z0)]];
+    const float t110 = s_rho[g.vol[voxel_offset(g, x1, y1, z0)]];
+    const float t001 = s_rho[g.vol[voxel_offset(g, x0, y0, z1)]];
+    const float t101 = s_rho[g.vol[voxel_offset(g, x1, y0, z1)]];
+    const float t011 = s_rho[g.vol[voxel_offset(g, x0, y1, z1)]];
+    const float t111 = s_rho[g.vol[voxel_offset(g, x1, y1, z1)]];
+    const float c00 = t000 * (1.0f - fx) + t100 * fx;
+    const float c10 = t010 * (1.0f - fx) + t110 * fx;
+    const float c01 = t001 * (1.0f - fx) + t101 * fx;
+    const float c11 = t011 * (1.0f - fx) + t111 * fx;
+    const float c0 = c00 * (1.0f - fy) + c10 * fy;
+    const float c1 = c01 * (1.0f - fy) + c11 * fy;
+    return c0 * (1.0f - fz) + c1 * fz;
+}
+
+__device__ __forceinline__ float sample_density(const Grid& g, const float* __restrict__ s_rho, bool linear, V3 p)
+{
+    if (linear) return fetch_linear(g, s_rho, p);
+    return s_rho[g.vol[nearest_offset(g, p)]];
+}
+
+__device__ __forceinline__ bool outside01(V3 p)
+{
+    return (p.x < 0.0f) | (p.y < 0.0f) | (p.z < 0.0f) | (p.x > 1.0f) | (p.y > 1.0f) | (p.z > 1.0f);
+}
+
+// wgsl:52-75, 5 taps along the ray, out-of-volume taps skipped  (EXACT)
+template <bool COUNT>
+__device__ __forceinline__ float sample_density_smoothed(const Grid& g, const float* __restrict__ s_rho,
+                                                         bool linear, const FrameParams& fp, V3 pos, V3 dir,
+                                                         uint32_t& n_vol)
+{
+    float sum = 0.0f, wsum = 0.0f;
+#pragma unroll
+    for (int i = -2; i <= 2; ++i) {
+        const float offset = static_cast<float>(i) * 0.005f;
+        const V3 sp = pos + dir * offset;
+        if (outside01(sp)) continue;
+        const float w = fp.gauss_w[i + 2];
+        const float s = sample_density(g, s_rho, linear, sp);
+        if (COUNT) n_vol++;
+        sum += s * w;
+        wsum += w;
+    }
+    return sum / wsum;
+}
+
+// transfer function, Linear/ClampToEdge, continuous rho  (EXACT in alpha, colour follows)
+__device__ __forceinline__ float4 sample_tf(const float4* __restrict__ s_lut, uint32_t tf_n, float u)
+{
+    int i0, i1;
+    float w;
+    texel_linear(u, static_cast<float>(tf_n), static_cast<int>(tf_n), i0, i1, w);
+    const float4 a = s_lut[i0], b = s_lut[i1];
+    const float iw = 1.0f - w;
+    return make_float4(a.x * iw + b.x * w, a.y * iw + b.y * w, a.z * iw + b.z * w, a.w * iw + b.w * w);
+}
+
+// wgsl:141-160  (EXACT)
+template <bool COUNT>
+__device__ __forceinline__ bool ahead_straight(const Grid& g, const FrameParams& fp, V3 cur, V3 dir, float t_exit,
+                                               uint32_t& n_imp)
+{
+    V3 pos = cur;
+    const int n = static_cast<int>(fp.ahead_steps);
+    const float step = (t_exit - length_exact(cur)) / static_cast<float>(n);
+    for (int i = 0; i < n; ++i) {
+        pos = pos + dir * step;
+        const uint32_t ib = g.imp[nearest_offset(g, pos)];
+        if (COUNT) n_imp++;
+        if (ib >= 128u) return true;   // i/255 >= 0.5  <=>  i >= 128
+    }
+    return false;
+}
+
+// wgsl:94-139  (EXACT)
+template <bool COUNT>
+__device__ __forceinline__ bool ahead_cone(const Grid& g, const FrameParams& fp, V3 cur, V3 dir, float t_exit,
+                                           uint32_t& n_imp)
+{
+    const int n = static_cast<int>(fp.ahead_steps);
+    const float step = (t_exit - length_exact(cur)) / static_cast<float>(n);
+    const V3 right = normalize_exact(cross(dir, v3(0.0f, 1.0f, 0.0f)));
+    const V3 new_up = cross(dir, right);
+    for (int c = 0; c < 8; ++c) {
+        const float xo = fp.cone_cos[c] * 0.2f;
+        const float yo = fp.cone_sin[c] * 0.2f;
+        const V3 sd = normalize_exact((dir + right * xo) + new_up * yo);
+        V3 pos = cur;
+        for (int i = 0; i < n; ++i) {
+            pos = pos + sd * step;
+            if (outside01(pos)) break;
+            const uint32_t ib = g.imp[nearest_offset(g, pos)];
+            if (COUNT) n_imp++;
+            if (ib >= 128u) return true;
+        }
+    }
+    return false;
+}
+
+// wgsl:190-211 given the six gradient taps  (COLOUR)
+__device__ __forceinline__ V3 blinn_phong(V3 color, V3 grad, V3 pos, V3 eye)
+{
+    const float g2 = dot_fast(grad, grad);
+    if (!(g2 > 0.0f)) return color;   // zero gradient: normalize gives NaN, length(NaN) > 0 is false
+    const float ginv = __builtin_amdgcn_rsqf(g2);
+    const V3 n = grad * ginv;
+    const float il = 0.57735026919f;   // normalize(1,1,1)
+    const V3 e = eye - pos;
+    const V3 E = e * __builtin_amdgcn_rsqf(dot_fast(e, e));
+    const V3 h = v3(E.x + il, E.y + il, E.z + il);
+    const V3 Hh = h * __builtin_amdgcn_rsqf(dot_fast(h, h));
+    const float diffuse = __builtin_fmaxf(0.0f, (n.x + n.y + n.z) * il);
+    float s = __builtin_fmaxf(0.0f, dot_fast(Hh, n));
+    const float s2 = s * s, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8;
+    const float spec = s16 * s8;       // ^24
+    const float kd = __builtin_fmaf(0.7f, diffuse, 0.2f);
+    const float ks = 0.4f * spec;
+    return v3(__builtin_fmaf(color.x, kd, ks), __builtin_fmaf(color.y, kd, ks), __builtin_fmaf(color.z, kd, ks));
+}
+
+// rgba8unorm store: clamp, scale, round to nearest
+__device__ __forceinline__ uint32_t to_unorm8(float v)
+{
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 1.0f) return 255u;
+    return static_cast<uint32_t>(__builtin_floorf(v * 255.0f + 0.5f));
+}
+
+__device__ __forceinline__ uint32_t pack_rgba8(float r, float g, float b, float a)
+{
+    return to_unorm8(r) | (to_unorm8(g) << 8) | (to_unorm8(b) << 16) | (to_unorm8(a) << 24);
+}
+
+struct Ray {
+    V3 o, d;
+    float t_entry, t_exit;
+    bool hit;
+};
+
+// wgsl:221-241  (EXACT)
+__device__ __forceinline__ Ray make_ray(const FrameParams& fp, uint32_t gx, uint32_t gy)
+{
+    Ray r;
+    const float scx = static_cast<float>(gx) / static_cast<float>(fp.W);
+    const float scy = static_cast<float>(gy) / static_cast<float>(fp.H);
+    const float ndx = scx * 2.0f - 1.0f;
+    const float ndy = 1.0f - scy * 2.0f;
+    float wp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        wp[k] = ((fp.ivp[k] * ndx + fp.ivp[4 + k] * ndy) + fp.ivp[8 + k] * 0.0f) + fp.ivp[12 + k] * 1.0f;
+    r.o = v3(fp.eye[0], fp.eye[1], fp.eye[2]);
+    const V3 world = v3(wp[0] / wp[3], wp[1] / wp[3], wp[2] / wp[3]);
+    r.d = normalize_exact(world - r.o);
+    const float t1x = (0.0f - r.o.x) / r.d.x, t2x = (1.0f - r.o.x) / r.d.x;
+    const float t1y = (0.0f - r.o.y) / r.d.y, t2y = (1.0f - r.o.y) / r.d.y;
+    const float t1z = (0.0f - r.o.z) / r.d.z, t2z = (1.0f - r.o.z) / r.d.z;
+    const float entry = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
+                                        __builtin_fminf(t1z, t2z));
+    const float exit_ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
+                                        __builtin_fmaxf(t1z, t2z));
+    r.t_entry = __builtin_fmaxf(entry, 0.0f);
+    r.t_exit = __builtin_fmaxf(exit_, 0.0f);
+    r.hit = !(r.t_exit <= r.t_entry);
+    return r;
+}
+
+}  // namespace volym

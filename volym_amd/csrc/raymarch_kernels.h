@@ -1,0 +1,312 @@
+// The ray-march kernels (gfx950).  One wave64 = one 8x8 pixel tile, one 256-thread
+// workgroup = one 16x16 screen tile (the reference's workgroup shape, wgsl:213).
+//
+//   VARIANT 0  "direct": every fetch the reference shader makes is issued (BASELINE config 2).
+//   VARIANT 1  "macro-cell": a (mc_n)^3 grid of per-cell density maxima lets a ray replay the
+//              step state machine through provably-empty cells without touching the volume
+//              (BASELINE config 3); the float arithmetic on t / cur_step is replayed exactly,
+//              so pixels are identical to VARIANT 0.
+//   COUNT      instrumented launch that counts the reference's fetches (volym_stats_pass).
+#pragma once
+
+#include "raymarch_device.h"
+
+namespace volym {
+
+// block -> tile.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each
+// with its own 4 MiB L2; giving each XCD contiguous screen bands keeps its slice of the volume
+// L2-resident.  bands == 0: identity.
+__device__ __forceinline__ uint32_t block_to_local_tile(uint32_t b, uint32_t n_local, uint32_t bands)
+{
+    if (bands == 0u) return b;
+    // n_local tiles are split into 8*bands chunks; XCD x owns chunks x, x+8, x+16, ...
+    const uint32_t xcd = b & 7u;
+    const uint32_t i = b >> 3;                      // i-th block of this XCD
+    const uint32_t chunks = 8u * bands;
+    const uint32_t per_chunk = (n_local + chunks - 1u) / chunks;
+    const uint32_t band = i / per_chunk;            // which of this XCD's chunks
+    const uint32_t within = i - band * per_chunk;
+    return (band * 8u + xcd) * per_chunk + within;  // may be >= n_local: caller guards
+}
+
+template <int VARIANT, bool COUNT>
+__global__ __launch_bounds__(256) void volym_raymarch_kernel(
+    const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
+    const uint8_t* __restrict__ mc_max, uint32_t* __restrict__ out_shard, uint32_t* __restrict__ out_raster,
+    float4* __restrict__ out_f32, Counters* __restrict__ counters, const FrameParams fp)
+{
+    __shared__ float4 s_tf_tab[256];
+    __shared__ float4 s_lut[256];
+    __shared__ float s_ic_alpha[256];
+    __shared__ float s_rho[256];
+
+    const uint32_t flags = fp.flags;
+    const bool linear = (flags & F_LINEAR) != 0u;
+    const bool gauss = (flags & F_GAUSSIAN) != 0u;
+    const bool table_mode = !linear && !gauss;      // rho is one of 256 values
+    const bool imp_coloring = (flags & F_IMP_COLORING) != 0u;
+    const bool imp_rendering = (flags & F_IMP_RENDERING) != 0u;
+
+    {
+        const uint32_t i = threadIdx.x;
+        s_tf_tab[i] = tables->tf_tab[i];
+        s_rho[i] = tables->rho[i];
+        if (!table_mode) s_lut[i] = tables->lut_f[i];
+        if (imp_coloring) s_ic_alpha[i] = tables->ic_alpha[i];
+    }
+    __syncthreads();
+
+    const uint32_t local_tile = block_to_local_tile(blockIdx.x, fp.n_local, fp.xcd_bands);
+    if (local_tile >= fp.n_local) return;
+    const uint32_t tile = local_tile * fp.world + fp.rank;
+    const uint32_t tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t px = ((wave & 1u) << 3) | (lane & 7u);
+    const uint32_t py = ((wave >> 1) << 3) | (lane >> 3);
+    const uint32_t gx = tx * 16u + px, gy = ty * 16u + py;
+    const bool in_frame = gx < fp.W && gy < fp.H;   // wgsl:217-219
+
+    Grid g;
+    g.vol = vol; g.imp = imp;
+    g.nx = static_cast<int>(fp.nx); g.ny = static_cast<int>(fp.ny); g.nz = static_cast<int>(fp.nz);
+    g.fnx = static_cast<float>(fp.nx); g.fny = static_cast<float>(fp.ny); g.fnz = static_cast<float>(fp.nz);
+    g.hix = static_cast<float>(fp.nx - 1u); g.hiy = static_cast<float>(fp.ny - 1u); g.hiz = static_cast<float>(fp.nz - 1u);
+
+    uint32_t n_vol = 0, n_imp = 0, n_steps = 0, n_dense = 0, n_hit = 0;
+    float out_r = 0.0f, out_g = 0.0f, out_b = 0.0f, out_a = 1.0f;   // miss: (0,0,0,1) wgsl:239
+
+    if (in_frame) {
+        const Ray ray = make_ray(fp, gx, gy);
+        if (ray.hit) {
+            if (COUNT) n_hit = 1;
+            const V3 eye = ray.o;
+            const float base = fp.base_step, min_step = fp.min_step, thr = fp.thr;
+            float t = ray.t_entry, cur = base;
+            V3 acc = v3(0.0f, 0.0f, 0.0f);
+            float acc_a = 0.0f;
+
+            // --- VARIANT 1 state: conservative "no sample in [t, t_safe) can be dense" ---
+            float t_safe = -1.0f;
+            const float mcf = static_cast<float>(fp.mc_n);
+            // reciprocal direction for cell-exit distances (conservative use only, not EXACT)
+            const float idx_ = 1.0f / ray.d.x, idy_ = 1.0f / ray.d.y, idz_ = 1.0f / ray.d.z;
+
+            while (t < ray.t_exit && acc_a < 0.95f) {             // wgsl:250
+                if (VARIANT == 1 && table_mode) {
+                    if (t < t_safe) {
+                        // Replay of an empty step: rho < thr is known, so (wgsl:263-274)
+                        // cur = min(base, cur*1.5); t += cur.  Fetches elided.
+                        if (COUNT) { n_steps++; n_vol++; n_imp++; }
+                        cur = __builtin_fminf(base, cur * 1.5f);
+                        t += cur;
+                        continue;
+                    }
+                }
+                const V3 pos = ray.o + ray.d * t;                 // wgsl:251
+                if (VARIANT == 1 && table_mode) {
+                    // macro cell of pos; its max byte decides whether the cell can hold a dense voxel
+                    const float cxf = __builtin_floorf(pos.x * mcf), cyf = __builtin_floorf(pos.y * mcf),
+                                czf = __builtin_floorf(pos.z * mcf);
+                    const float hi = mcf - 1.0f;
+                    const bool inside = cxf >= 0.0f && cyf >= 0.0f && czf >= 0.0f && cxf <= hi && cyf <= hi && czf <= hi;
+                    if (inside) {
+                        const uint32_t ci = static_cast<uint32_t>(cxf) +
+                                            fp.mc_n * (static_cast<uint32_t>(cyf) + fp.mc_n * static_cast<uint32_t>(czf));
+                        if (static_cast<uint32_t>(mc_max[ci]) < fp.thr_byte) {
+                            // distance along the ray until pos leaves the cell shrunk by eps on every face
+                            const float inv = 1.0f / mcf;
+                            const float eps = 4.0e-5f;
+                            const float x0 = cxf * inv + eps, x1 = (cxf + 1.0f) * inv - eps;
+                            const float y0 = cyf * inv + eps, y1 = (cyf + 1.0f) * inv - eps;
+                            const float z0 = czf * inv + eps, z1 = (czf + 1.0f) * inv - eps;
+                            const bool within = pos.x > x0 && pos.x < x1 && pos.y > y0 && pos.y < y1 && pos.z > z0 && pos.z < z1;
+                            if (within) {
+                                const float ex = ((ray.d.x >= 0.0f ? x1 : x0) - ray.o.x) * idx_;
+                                const float ey = ((ray.d.y >= 0.0f ? y1 : y0) - ray.o.y) * idy_;
+                                const float ez = ((ray.d.z >= 0.0f ? z1 : z0) - ray.o.z) * idz_;
+                                // NaN/inf (d component 0) drop out of fmin; relative slack covers rounding
+                                float te = __builtin_fminf(__builtin_fminf(ex, ey), ez);
+                                te = te - 1.0e-5f * __builtin_fabsf(te);
+                                if (te > t) t_safe = te;
+                            }
+                        }
+                    }
+                    if (t < t_safe) {
+                        if (COUNT) { n_steps++; n_vol++; n_imp++; }
+                        cur = __builtin_fminf(base, cur * 1.5f);
+                        t += cur;
+                        continue;
+                    }
+                }
+                if (COUNT) n_steps++;
+
+                // ---- density (wgsl:253-259) and the step state machine (wgsl:263-274) ----
+                int ix = 0, iy = 0, iz = 0;
+                uint32_t off = 0, b = 0;
+                float rho = 0.0f;
+                bool dense;
+                if (table_mode) {
+                    ix = texel_nearest(pos.x, g.fnx, g.hix);
+                    iy = texel_nearest(pos.y, g.fny, g.hiy);
+                    iz = texel_nearest(pos.z, g.fnz, g.hiz);
+                    off = voxel_offset(g, ix, iy, iz);
+                    b = vol[off];
+                    if (COUNT) n_vol++;
+                    dense = b >= fp.thr_byte;                     // <=> b/255 >= thr
+                } else {
+                    if (gauss) rho = sample_density_smoothed<COUNT>(g, s_rho, linear, fp, pos, ray.d, n_vol);
+                    else { rho = sample_density(g, s_rho, linear, pos); if (COUNT) n_vol++; }
+                    dense = rho >= thr;
+                    off = nearest_offset(g, pos);                 // importance texel (always nearest)
+                }
+                if (COUNT) n_imp++;                               // wgsl:260 fetches it every step
+                cur = dense ? min_step : __builtin_fminf(base, cur * 1.5f);
+                if (!dense) { t += cur; continue; }
+                if (COUNT) n_dense++;
+
+                // ---- classification (wgsl:276-304) ----
+                float cr, cg, cb, alpha_step;
+                bool use_alpha = (flags & F_OPACITY) != 0u;
+                if (imp_coloring) {                               // wgsl:83-92
+                    const uint32_t ib = imp[off];
+                    const float im = s_rho[ib];
+                    cr = __builtin_fminf(im * 1.5f, 1.0f);
+                    cg = (1.0f - im) * 1.2f;
+                    cb = 0.2f;
+                    alpha_step = s_ic_alpha[ib];
+                    use_alpha = true;
+                } else {
+                    if (imp_rendering) {                          // wgsl:283-295
+                        const uint32_t ib = imp[off];
+                        const bool ahead = (flags & F_CONE) ? ahead_cone<COUNT>(g, fp, pos, ray.d, ray.t_exit, n_imp)
+                                                            : ahead_straight<COUNT>(g, fp, pos, ray.d, ray.t_exit, n_imp);
+                        if (ib < 255u && ahead) { t += cur; continue; }   // importance < 1.0 && ahead
+                    }
+                    if (table_mode) {
+                        const float4 ca = s_tf_tab[b];
+                        cr = ca.x; cg = ca.y; cb = ca.z; alpha_step = ca.w;
+                    } else {
+                        const float4 ca = sample_tf(s_lut, fp.tf_n, rho);   // wgsl:297-303
+                        cr = ca.x; cg = ca.y; cb = ca.z;
+                        alpha_step = 1.0f - wgsl_pow(1.0f - ca.w, fp.alpha_y);   // wgsl:314
+                    }
+                }
+
+                // ---- gradient taps (wgsl:181-188) ----
+                V3 grad;
+                const float o = 0.01f;
+                if (table_mode) {
+                    const int ixp = texel_nearest(pos.x + o, g.fnx, g.hix), ixm = texel_nearest(pos.x - o, g.fnx, g.hix);
+                    const int iyp = texel_nearest(pos.y + o, g.fny, g.hiy), iym = texel_nearest(pos.y - o, g.fny, g.hiy);
+                    const int izp = texel_nearest(pos.z + o, g.fnz, g.hiz), izm = texel_nearest(pos.z - o, g.fnz, g.hiz);
+                    const uint32_t bxp = vol[voxel_offset(g, ixp, iy, iz)], bxm = vol[voxel_offset(g, ixm, iy, iz)];
+                    const uint32_t byp = vol[voxel_offset(g, ix, iyp, iz)], bym = vol[voxel_offset(g, ix, iym, iz)];
+                    const uint32_t bzp = vol[voxel_offset(g, ix, iy, izp)], bzm = vol[voxel_offset(g, ix, iy, izm)];
+                    grad = v3(s_rho[bxp] - s_rho[bxm], s_rho[byp] - s_rho[bym], s_rho[bzp] - s_rho[bzm]);
+                } else {
+                    grad = v3(sample_density(g, s_rho, linear, v3(pos.x + o, pos.y, pos.z)) -
+                                  sample_density(g, s_rho, linear, v3(pos.x - o, pos.y, pos.z)),
+                              sample_density(g, s_rho, linear, v3(pos.x, pos.y + o, pos.z)) -
+                                  sample_density(g, s_rho, linear, v3(pos.x, pos.y - o, pos.z)),
+                              sample_density(g, s_rho, linear, v3(pos.x, pos.y, pos.z + o)) -
+                                  sample_density(g, s_rho, linear, v3(pos.x, pos.y, pos.z - o)));
+                }
+                if (COUNT) n_vol += 6;
+                // the common 1/(2*0.01) factor cancels in normalize()
+                const V3 shaded = blinn_phong(v3(cr, cg, cb), grad, pos, eye);   // wgsl:306-311
+
+                if (use_alpha) {                                  // wgsl:313-318
+                    const float w = (1.0f - acc_a) * alpha_step;
+                    acc = v3(__builtin_fmaf(shaded.x, w, acc.x), __builtin_fmaf(shaded.y, w, acc.y),
+                             __builtin_fmaf(shaded.z, w, acc.z));
+                    acc_a += w;
+                } else {                                          // wgsl:319-323
+                    acc = shaded;
+                    acc_a = 1.0f;
+                    break;
+                }
+                t += cur;                                         // wgsl:325
+            }
+            out_r = acc.x; out_g = acc.y; out_b = acc.z; out_a = acc_a;
+        }
+
+        // ---- store (wgsl:328-329; rgba8unorm) ----
+        const uint32_t packed = pack_rgba8(out_r, out_g, out_b, out_a);
+        if (flags & F_RASTER) {
+            const size_t o = static_cast<size_t>(gy) * fp.W + gx;
+            out_raster[o] = packed;
+            if (flags & F_WRITE_F32) out_f32[o] = make_float4(out_r, out_g, out_b, out_a);
+        } else {
+            out_shard[static_cast<size_t>(local_tile) * 256u + threadIdx.x] = packed;
+        }
+    } else if (!(flags & F_RASTER)) {
+        out_shard[static_cast<size_t>(local_tile) * 256u + threadIdx.x] = 0u;
+    }
+
+    if (COUNT) {
+        unsigned long long v[5] = {n_vol, n_imp, n_steps, n_dense, n_hit};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            unsigned long long x = v[k];
+            for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s, 64);
+            v[k] = x;
+        }
+        if (lane == 0) {
+            atomicAdd(&counters->n_vol, v[0]);
+            atomicAdd(&counters->n_imp, v[1]);
+            atomicAdd(&counters->n_steps, v[2]);
+            atomicAdd(&counters->n_dense, v[3]);
+            atomicAdd(&counters->n_hit, v[4]);
+        }
+    }
+}
+
+// per-cell maxima of the density volume: cell (cx,cy,cz) of the mc_n^3 grid covers the voxels a
+// nearest-filter sample with pos in [c/mc_n, (c+1)/mc_n) can select, i.e. floor(pos*n) for those pos.
+__global__ __launch_bounds__(256) void volym_macrocell_kernel(const uint8_t* __restrict__ vol, uint8_t* __restrict__ mc_max,
+                                                              uint32_t nx, uint32_t ny, uint32_t nz, uint32_t mc_n)
+{
+    const uint32_t cell = blockIdx.x;
+    const uint32_t cx = cell % mc_n, cy = (cell / mc_n) % mc_n, cz = cell / (mc_n * mc_n);
+    // voxel range [lo, hi) per axis, one voxel of slack on both sides (float rounding of pos*n)
+    auto lo = [&](uint32_t c, uint32_t n) { uint32_t v = static_cast<uint32_t>((static_cast<uint64_t>(c) * n) / mc_n); return v > 0u ? v - 1u : 0u; };
+    auto hi = [&](uint32_t c, uint32_t n) { uint32_t v = static_cast<uint32_t>((static_cast<uint64_t>(c + 1u) * n + mc_n - 1u) / mc_n) + 1u; return v < n ? v : n; };
+    const uint32_t x0 = lo(cx, nx), x1 = hi(cx, nx), y0 = lo(cy, ny), y1 = hi(cy, ny), z0 = lo(cz, nz), z1 = hi(cz, nz);
+    const uint32_t wx = x1 - x0, wy = y1 - y0, wz = z1 - z0;
+    const uint32_t total = wx * wy * wz;
+    uint32_t m = 0;
+    for (uint32_t i = threadIdx.x; i < total; i += 256u) {
+        const uint32_t x = x0 + i % wx, y = y0 + (i / wx) % wy, z = z0 + i / (wx * wy);
+        const uint32_t v = vol[static_cast<size_t>(x) + static_cast<size_t>(nx) * (y + static_cast<size_t>(ny) * z)];
+        m = v > m ? v : m;
+    }
+    for (int s = 32; s > 0; s >>= 1) { const uint32_t o = __shfl_xor(m, s, 64); m = o > m ? o : m; }
+    __shared__ uint32_t s_m[4];
+    if ((threadIdx.x & 63u) == 0u) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t r = s_m[0];
+        for (int w = 1; w < 4; ++w) r = s_m[w] > r ? s_m[w] : r;
+        mc_max[cell] = static_cast<uint8_t>(r);
+    }
+}
+
+// root side of the image gather: world shards of 16x16 tiles -> W x H raster
+__global__ __launch_bounds__(256) void volym_assemble_kernel(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ raster,
+                                                             uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
+                                                             uint32_t world, uint32_t shard_tiles)
+{
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const uint32_t rank = tile % world, local = tile / world;
+    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t px = ((wave & 1u) << 3) | (lane & 7u);
+    const uint32_t py = ((wave >> 1) << 3) | (lane >> 3);
+    const uint32_t gx = tx * 16u + px, gy = ty * 16u + py;
+    if (gx < W && gy < H)
+        raster[static_cast<size_t>(gy) * W + gx] =
+            gathered[(static_cast<size_t>(rank) * shard_tiles + local) * 256u + threadIdx.x];
+}
+
+}  // namespace volym
