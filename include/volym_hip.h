@@ -50,10 +50,12 @@ enum { VOLYM_FILTER_NEAREST = 0, VOLYM_FILTER_LINEAR = 1 };
 /* volym_set_option keys */
 enum {
     VOLYM_OPT_KERNEL = 1,     /* 0 = direct march (every reference fetch issued),
-                                 1 = macro-cell march (default): empty-space fetches elided,
-                                     step arithmetic replayed exactly                     */
+                                 1 = macro-cell march: empty-space fetches elided, step
+                                     arithmetic replayed exactly,
+                                 2 = (default) 1 + persistent workgroups, centre-first tile
+                                     order, per-wave shading queue, speculative sample batches */
     VOLYM_OPT_WRITE_F32 = 2,  /* 1 = also store pre-quantisation float RGBA (parity tests) */
-    VOLYM_OPT_MACRO_CELLS = 3 /* macro cells per axis (power of two, 4..64; default 32)    */
+    VOLYM_OPT_MACRO_CELLS = 3 /* macro cells per axis (power of two, 4..32; default 32)    */
 };
 
 /* CameraUniforms, byte-for-byte (src/gpu_resources/camera.rs:56-64; WGSL mirror

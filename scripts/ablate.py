@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Ablation timings of the march kernel (development aid, not part of the bench contract)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from volym_amd import _lib, demo, scene, synth  # noqa: E402
+
+
+def cam_uniforms(aspect, position, target):
+    cam = scene.Camera.default_with_aspect_and_pos(aspect, position)
+    cam.c.target = (C.c_float * 3)(*target)
+    return cam.uniforms()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=50)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bands", type=int, nargs="*", default=[0])
+    ap.add_argument("--kernels", type=int, nargs="*", default=[0, 1])
+    ap.add_argument("--cases", nargs="*", default=["bench", "miss", "empty", "solid"])
+    ap.add_argument("--step", type=float, default=0.01)
+    args = ap.parse_args()
+    W, H = args.width, args.height
+    dims = (256, 256, 256)
+    raw = synth.synth_bonsai(256)
+    vol = scene.prepare_volume(raw, dims, True)
+    zeros = np.zeros(256 ** 3, np.uint8)
+    params = scene.StateParameters.benchmark().replace(raymarching_step_size=args.step)
+    state = scene.State.with_parameters(W / H, params)
+    state.update()
+    pu = state.parameter_uniforms()
+    cases = {
+        "bench": (vol, state.camera_uniforms()),
+        "miss": (vol, cam_uniforms(W / H, (0.5, 0.5, 1.5), (0.5, 0.5, 2.5))),
+        "empty": (zeros, state.camera_uniforms()),
+        "solid": (np.full(256 ** 3, 200, np.uint8), state.camera_uniforms()),
+    }
+    with demo.GpuContext(W, H, 0) as ctx:
+        ctx.set_importances(zeros, dims)
+        ctx.set_transfer_function(scene.default_lut())
+        for name in args.cases:
+            v, cu = cases[name]
+            ctx.set_volume(v, dims)
+            for k in args.kernels:
+                for b in args.bands:
+                    ctx.set_option(_lib.OPT_KERNEL, k)
+                    ctx.set_option(_lib.OPT_XCD_BANDS, b)
+                    ctx.update(cu, pu)
+                    ctx.time_passes(5)
+                    ms = ctx.time_passes(args.n)
+                    st = ctx.stats_pass()
+                    print("%-6s kernel %d bands %2d: %8.1f us (min %7.1f)  steps %10d dense %9d hit %8d" %
+                          (name, k, b, 1e3 * float(np.mean(ms)), 1e3 * float(ms.min()), st["n_steps"], st["n_dense"], st["n_hit"]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,9 @@
 
 #include "../../include/volym_hip.h"
 #include "raymarch_kernels.h"
+#include "raymarch_pq.h"
+
+#include <algorithm>
 
 using namespace volym;
 
@@ -44,8 +47,10 @@ struct volym_ctx {
     bool tables_dirty = true;
     float tables_alpha_y = -1.0f;
 
-    uint8_t* d_mc = nullptr;
+    uint8_t* d_mc = nullptr;   // per-macro-cell density maxima
+    uint8_t* d_df = nullptr;   // packed 4-bit distance field for (d_mc, thr_byte)
     uint32_t mc_n = 32, mc_built_n = 0;
+    uint32_t df_thr_byte = 0xffffffffu;
     bool mc_dirty = true;
 
     uint32_t* d_shard_own = nullptr;
@@ -56,9 +61,15 @@ struct volym_ctx {
     uint8_t* d_gather_tmp = nullptr;
     size_t gather_tmp_bytes = 0;
     Counters* d_counters = nullptr;
+    uint4* d_trace = nullptr;   // development aid, see volym_dev_wave_trace
+    uint32_t* d_order = nullptr;   // variant 2: this rank's 8x8 wave tiles, centre-first
+    uint32_t n_items = 0;
+    bool order_dirty = true;
+    int n_cus = 256;
+    uint32_t wgs_per_cu = 2;
 
     FrameParams fp;
-    int kernel_variant = 1;
+    int kernel_variant = 2;
     bool write_f32 = false;
     uint32_t xcd_bands = 0;
     std::string err;
@@ -113,6 +124,7 @@ int volym_create(volym_ctx** out, uint32_t width, uint32_t height, int device_id
     volym_ctx* c = new (std::nothrow) volym_ctx();
     if (!c) return fail(nullptr, VOLYM_E_NOMEM, "volym_create: out of host memory");
     c->device = dev;
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->W = width; c->H = height;
     c->tiles_x = (width + 15u) / 16u;     // src/demos/pipeline.rs:83-87
     c->tiles_y = (height + 15u) / 16u;
@@ -146,9 +158,9 @@ void volym_destroy(volym_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->d_vol); (void)hipFree(c->d_imp); (void)hipFree(c->d_tables); (void)hipFree(c->d_mc);
+    (void)hipFree(c->d_vol); (void)hipFree(c->d_imp); (void)hipFree(c->d_tables); (void)hipFree(c->d_mc); (void)hipFree(c->d_df);
     (void)hipFree(c->d_shard_own); (void)hipFree(c->d_frame_own); (void)hipFree(c->d_f32);
-    (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_counters); (void)hipFree(c->d_order);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -167,17 +179,21 @@ int volym_set_option(volym_ctx* c, int key, int value)
     if (!c) return VOLYM_E_INVALID;
     switch (key) {
     case VOLYM_OPT_KERNEL:
-        if (value != 0 && value != 1) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_KERNEL: 0 (direct) or 1 (macro-cell)");
+        if (value < 0 || value > 2) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_KERNEL: 0 (direct), 1 (macro-cell) or 2 (persistent + shading queue)");
         c->kernel_variant = value;
         return VOLYM_OK;
     case VOLYM_OPT_WRITE_F32:
         c->write_f32 = value != 0;
         return VOLYM_OK;
     case VOLYM_OPT_MACRO_CELLS:
-        if (value < 4 || value > 64 || (value & (value - 1)) != 0)
-            return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_MACRO_CELLS: power of two in 4..64");
+        if (value < 4 || value > 32 || (value & (value - 1)) != 0)
+            return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_MACRO_CELLS: power of two in 4..32");
         c->mc_n = static_cast<uint32_t>(value);
         c->mc_dirty = true;
+        return VOLYM_OK;
+    case 101:   // undocumented tuning knob: persistent workgroups per CU (variant 2)
+        if (value < 1 || value > 8) return fail(c, VOLYM_E_INVALID, "workgroups per CU: 1..8");
+        c->wgs_per_cu = static_cast<uint32_t>(value);
         return VOLYM_OK;
     case 100:   // undocumented tuning knob: block->tile remap bands per XCD (0 = identity)
         if (value < 0 || value > 64) return fail(c, VOLYM_E_INVALID, "xcd bands: 0..64");
@@ -194,6 +210,7 @@ int volym_set_shard(volym_ctx* c, uint32_t rank, uint32_t world)
     if (world == 0 || rank >= world || world > 4096) return fail(c, VOLYM_E_INVALID, "volym_set_shard: need rank < world <= 4096");
     c->rank = rank; c->world = world;
     recompute_shard(c);
+    c->order_dirty = true;
     return VOLYM_OK;
 }
 
@@ -285,21 +302,68 @@ static void build_tables(volym_ctx* c, float alpha_y)
     }
 }
 
+// Variant 2 work list: the 8x8-pixel wave tiles of this rank's 16x16 tiles (item = local_tile*4 + sub),
+// sorted by Chebyshev distance of the tile centre from the screen centre.  The orbit camera always
+// targets the volume centre (src/camera.rs:23), so the long rays are the central ones: they start first.
+static int build_order(volym_ctx* c)
+{
+    std::vector<std::pair<uint32_t, uint32_t>> keyed;
+    keyed.reserve(static_cast<size_t>(c->n_local) * 4);
+    for (uint32_t lt = 0; lt < c->n_local; ++lt) {
+        const uint32_t tile = lt * c->world + c->rank;
+        const uint32_t tx = tile % c->tiles_x, ty = tile / c->tiles_x;
+        for (uint32_t sub = 0; sub < 4; ++sub) {
+            const int x0 = static_cast<int>(tx * 16u + (sub & 1u) * 8u), y0 = static_cast<int>(ty * 16u + (sub >> 1) * 8u);
+            if (x0 >= static_cast<int>(c->W) || y0 >= static_cast<int>(c->H)) {
+                if (c->world == 1) continue;          // wholly outside the frame: nothing to store in raster mode
+            }
+            const int dx = std::abs(2 * x0 + 8 - static_cast<int>(c->W)), dy = std::abs(2 * y0 + 8 - static_cast<int>(c->H));
+            keyed.emplace_back(static_cast<uint32_t>(std::max(dx, dy)), lt * 4u + sub);
+        }
+    }
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<uint32_t> order(keyed.size());
+    for (size_t i = 0; i < keyed.size(); ++i) order[i] = keyed[i].second;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_order) { HIPCHK(c, hipFree(c->d_order)); c->d_order = nullptr; }
+    c->n_items = static_cast<uint32_t>(order.size());
+    if (c->n_items) {
+        hipError_t e = hipMalloc(&c->d_order, order.size() * sizeof(uint32_t));
+        if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(order): ") + hipGetErrorString(e));
+        HIPCHK(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    c->order_dirty = false;
+    return VOLYM_OK;
+}
+
 static int ensure_frame_resources(volym_ctx* c)
 {
+    if (c->order_dirty) {
+        int rc = build_order(c);
+        if (rc != VOLYM_OK) return rc;
+    }
     if (c->write_f32 && !c->d_f32) {
         hipError_t e = hipMalloc(&c->d_f32, static_cast<size_t>(c->W) * c->H * sizeof(float4));
         if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(f32 frame): ") + hipGetErrorString(e));
     }
     if (c->mc_dirty || c->mc_built_n != c->mc_n) {
         if (c->d_mc) { HIPCHK(c, hipFree(c->d_mc)); c->d_mc = nullptr; }
+        if (c->d_df) { HIPCHK(c, hipFree(c->d_df)); c->d_df = nullptr; }
         const uint32_t cells = c->mc_n * c->mc_n * c->mc_n;
         hipError_t e = hipMalloc(&c->d_mc, cells);
+        if (e == hipSuccess) e = hipMalloc(&c->d_df, (cells / 2u + 15u) / 16u * 16u);
         if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(macro cells): ") + hipGetErrorString(e));
         hipLaunchKernelGGL(volym_macrocell_kernel, dim3(cells), dim3(256), 0, c->stream, c->d_vol, c->d_mc, c->nx, c->ny, c->nz, c->mc_n);
         HIPCHK(c, hipGetLastError());
         c->mc_dirty = false;
         c->mc_built_n = c->mc_n;
+        c->df_thr_byte = 0xffffffffu;
+    }
+    if (c->df_thr_byte != c->fp.thr_byte) {
+        // stream order: earlier frames finish reading d_df before this kernel rewrites it
+        hipLaunchKernelGGL(volym_distance_field_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_mc, c->d_df, c->mc_n, c->fp.thr_byte);
+        HIPCHK(c, hipGetLastError());
+        c->df_thr_byte = c->fp.thr_byte;
     }
     return VOLYM_OK;
 }
@@ -366,7 +430,7 @@ int volym_update(volym_ctx* c, const volym_camera_uniforms* cam, const volym_par
 
 }  // extern "C"
 
-template <bool COUNT>
+template <bool COUNT, bool TRACE = false>
 static int launch_march(volym_ctx* c)
 {
     int rc = ensure_frame_resources(c);
@@ -385,12 +449,27 @@ static int launch_march(volym_ctx* c)
         grid = per_chunk * chunks;
     }
     Counters* cnt = COUNT ? c->d_counters : nullptr;
-    if (c->kernel_variant == 1)
-        hipLaunchKernelGGL((volym_raymarch_kernel<1, COUNT>), dim3(grid), dim3(256), 0, c->stream, c->d_vol, c->d_imp, c->d_tables,
-                           c->d_mc, c->d_shard, c->d_frame, c->d_f32, cnt, fp);
+    uint4* trace = TRACE ? c->d_trace : nullptr;
+    if (c->kernel_variant == 2 && !TRACE) {
+        if (c->n_items == 0) return VOLYM_OK;
+        const uint32_t want = (c->n_items + PQ_WAVES - 1) / PQ_WAVES;
+        const uint32_t pgrid = std::min(want, static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu);
+        const bool table = !(fp.flags & (F_LINEAR | F_GAUSSIAN));
+        if (table)
+            hipLaunchKernelGGL((volym_raymarch_pq_kernel<true, COUNT>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol, c->d_imp,
+                               c->d_tables, c->d_df, c->d_order, c->n_items, c->d_shard, c->d_frame, c->d_f32, cnt, fp);
+        else
+            hipLaunchKernelGGL((volym_raymarch_pq_kernel<false, COUNT>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol, c->d_imp,
+                               c->d_tables, c->d_df, c->d_order, c->n_items, c->d_shard, c->d_frame, c->d_f32, cnt, fp);
+        HIPCHK(c, hipGetLastError());
+        return VOLYM_OK;
+    }
+    if (c->kernel_variant >= 1)
+        hipLaunchKernelGGL((volym_raymarch_kernel<1, COUNT, TRACE>), dim3(grid), dim3(256), 0, c->stream, c->d_vol, c->d_imp, c->d_tables,
+                           c->d_df, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp);
     else
-        hipLaunchKernelGGL((volym_raymarch_kernel<0, COUNT>), dim3(grid), dim3(256), 0, c->stream, c->d_vol, c->d_imp, c->d_tables,
-                           c->d_mc, c->d_shard, c->d_frame, c->d_f32, cnt, fp);
+        hipLaunchKernelGGL((volym_raymarch_kernel<0, COUNT, TRACE>), dim3(grid), dim3(256), 0, c->stream, c->d_vol, c->d_imp, c->d_tables,
+                           c->d_df, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp);
     HIPCHK(c, hipGetLastError());
     return VOLYM_OK;
 }
@@ -507,6 +586,33 @@ int volym_stats_pass(volym_ctx* c, volym_stats* out)
     }
     out->n_rays = rays;
     return VOLYM_OK;
+}
+
+// Development aid (not declared in the public header): one instrumented launch that records, per
+// wave, {start tick, duration ticks (100 MHz), max loop iterations of a lane, max dense samples}.
+// out: 4 * grid_blocks uint4 records; returns the number of records or a negative error.
+int volym_dev_wave_trace(volym_ctx* c, uint32_t* out, uint32_t max_records)
+{
+    if (!c || !out) return VOLYM_E_INVALID;
+    if (!c->have_frame) return fail(c, VOLYM_E_STATE, "volym_dev_wave_trace: call volym_update first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t records = (c->n_local + 64u) * 4u * 2u;
+    if (max_records < records) return fail(c, VOLYM_E_INVALID, "volym_dev_wave_trace: buffer too small");
+    HIPCHK(c, hipMalloc(&c->d_trace, static_cast<size_t>(records) * sizeof(uint4)));
+    HIPCHK(c, hipMemsetAsync(c->d_trace, 0, static_cast<size_t>(records) * sizeof(uint4), c->stream));
+    // a lone launch on an idle GPU runs at idle clocks: trace the 31st of 31 back-to-back passes
+    int rc = VOLYM_OK;
+    for (int i = 0; i < 30 && rc == VOLYM_OK; ++i) rc = launch_march<false, false>(c);
+    if (rc == VOLYM_OK) rc = launch_march<false, true>(c);
+    if (rc == VOLYM_OK) {
+        hipError_t e = hipMemcpyAsync(out, c->d_trace, static_cast<size_t>(records) * sizeof(uint4), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, VOLYM_E_HIP, hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_trace);
+    c->d_trace = nullptr;
+    return rc == VOLYM_OK ? static_cast<int>(records) : rc;
 }
 
 int volym_time_passes(volym_ctx* c, uint32_t n, float* ms_each)

@@ -29,30 +29,125 @@ __device__ __forceinline__ uint32_t block_to_local_tile(uint32_t b, uint32_t n_l
     return (band * 8u + xcd) * per_chunk + within;  // may be >= n_local: caller guards
 }
 
-template <int VARIANT, bool COUNT>
+// One dense sample: classification (wgsl:276-304), gradient + Blinn-Phong (wgsl:181-211) and
+// compositing (wgsl:313-325).  Returns 0 when the march goes on (t already advanced), 1 on the
+// first-hit break (wgsl:319-323).
+struct MarchCtx {
+    const float4* s_tf_tab;
+    const float4* s_lut;
+    const float* s_ic_alpha;
+    const float* s_rho;
+    uint32_t flags;
+    bool linear, table_mode;
+};
+
+template <bool COUNT>
+__device__ __forceinline__ int dense_sample(const MarchCtx& m, const Grid& g, const FrameParams& fp, const Ray& ray, V3 pos,
+                                            int ix, int iy, int iz, uint32_t off, uint32_t b, float rho, float& t, float cur,
+                                            V3& acc, float& acc_a, uint32_t& n_vol, uint32_t& n_imp)
+{
+    float cr, cg, cb, alpha_step;
+    bool use_alpha = (m.flags & F_OPACITY) != 0u;
+    if (m.flags & F_IMP_COLORING) {                              // wgsl:83-92
+        const uint32_t ib = g.imp[off];
+        const float im = m.s_rho[ib];
+        cr = __builtin_fminf(im * 1.5f, 1.0f);
+        cg = (1.0f - im) * 1.2f;
+        cb = 0.2f;
+        alpha_step = m.s_ic_alpha[ib];
+        use_alpha = true;
+    } else {
+        if (m.flags & F_IMP_RENDERING) {                         // wgsl:283-295
+            const uint32_t ib = g.imp[off];
+            const bool ahead = (m.flags & F_CONE) ? ahead_cone<COUNT>(g, fp, pos, ray.d, ray.t_exit, n_imp)
+                                                  : ahead_straight<COUNT>(g, fp, pos, ray.d, ray.t_exit, n_imp);
+            if (ib < 255u && ahead) { t += cur; return 0; }      // importance < 1.0 && ahead
+        }
+        if (m.table_mode) {
+            const float4 ca = m.s_tf_tab[b];
+            cr = ca.x; cg = ca.y; cb = ca.z; alpha_step = ca.w;
+        } else {
+            const float4 ca = sample_tf(m.s_lut, fp.tf_n, rho);  // wgsl:297-303
+            cr = ca.x; cg = ca.y; cb = ca.z;
+            alpha_step = 1.0f - wgsl_pow(1.0f - ca.w, fp.alpha_y);   // wgsl:314
+        }
+    }
+
+    // ---- gradient taps (wgsl:181-188) ----
+    V3 grad;
+    const float o = 0.01f;
+    if (m.table_mode) {
+        const int ixp = texel_nearest(pos.x + o, g.fnx, g.hix), ixm = texel_nearest(pos.x - o, g.fnx, g.hix);
+        const int iyp = texel_nearest(pos.y + o, g.fny, g.hiy), iym = texel_nearest(pos.y - o, g.fny, g.hiy);
+        const int izp = texel_nearest(pos.z + o, g.fnz, g.hiz), izm = texel_nearest(pos.z - o, g.fnz, g.hiz);
+        const uint32_t bxp = g.vol[voxel_offset(g, ixp, iy, iz)], bxm = g.vol[voxel_offset(g, ixm, iy, iz)];
+        const uint32_t byp = g.vol[voxel_offset(g, ix, iyp, iz)], bym = g.vol[voxel_offset(g, ix, iym, iz)];
+        const uint32_t bzp = g.vol[voxel_offset(g, ix, iy, izp)], bzm = g.vol[voxel_offset(g, ix, iy, izm)];
+        grad = v3(m.s_rho[bxp] - m.s_rho[bxm], m.s_rho[byp] - m.s_rho[bym], m.s_rho[bzp] - m.s_rho[bzm]);
+    } else {
+        grad = v3(sample_density(g, m.s_rho, m.linear, v3(pos.x + o, pos.y, pos.z)) -
+                      sample_density(g, m.s_rho, m.linear, v3(pos.x - o, pos.y, pos.z)),
+                  sample_density(g, m.s_rho, m.linear, v3(pos.x, pos.y + o, pos.z)) -
+                      sample_density(g, m.s_rho, m.linear, v3(pos.x, pos.y - o, pos.z)),
+                  sample_density(g, m.s_rho, m.linear, v3(pos.x, pos.y, pos.z + o)) -
+                      sample_density(g, m.s_rho, m.linear, v3(pos.x, pos.y, pos.z - o)));
+    }
+    if (COUNT) n_vol += 6;
+    // the common 1/(2*0.01) factor cancels in normalize()
+    const V3 shaded = blinn_phong(v3(cr, cg, cb), grad, pos, ray.o);   // wgsl:306-311
+
+    if (use_alpha) {                                             // wgsl:313-318
+        const float w = (1.0f - acc_a) * alpha_step;
+        acc = v3(__builtin_fmaf(shaded.x, w, acc.x), __builtin_fmaf(shaded.y, w, acc.y), __builtin_fmaf(shaded.z, w, acc.z));
+        acc_a += w;
+        t += cur;                                                // wgsl:325
+        return 0;
+    }
+    acc = shaded;                                                // wgsl:319-323
+    acc_a = 1.0f;
+    return 1;
+}
+
+// LDS bytes of the packed 4-bit distance field for the largest macro grid (32^3 cells)
+#define VOLYM_DF_LDS_BYTES 16384
+
+template <int VARIANT, bool COUNT, bool TRACE>
 __global__ __launch_bounds__(256) void volym_raymarch_kernel(
     const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
-    const uint8_t* __restrict__ mc_max, uint32_t* __restrict__ out_shard, uint32_t* __restrict__ out_raster,
-    float4* __restrict__ out_f32, Counters* __restrict__ counters, const FrameParams fp)
+    const uint8_t* __restrict__ df4, uint32_t* __restrict__ out_shard, uint32_t* __restrict__ out_raster,
+    float4* __restrict__ out_f32, Counters* __restrict__ counters, uint4* __restrict__ trace, const FrameParams fp)
 {
+    // development aid (TRACE launches only): per-wave start/end on the 100 MHz realtime counter
+    unsigned long long trace_t0 = 0;
+    uint32_t trace_iters = 0, trace_dense = 0;
+    if (TRACE) trace_t0 = __builtin_amdgcn_s_memrealtime();
     __shared__ float4 s_tf_tab[256];
     __shared__ float4 s_lut[256];
     __shared__ float s_ic_alpha[256];
     __shared__ float s_rho[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_df[VARIANT == 1 ? VOLYM_DF_LDS_BYTES : 16];
 
     const uint32_t flags = fp.flags;
-    const bool linear = (flags & F_LINEAR) != 0u;
+    MarchCtx m;
+    m.s_tf_tab = s_tf_tab; m.s_lut = s_lut; m.s_ic_alpha = s_ic_alpha; m.s_rho = s_rho;
+    m.flags = flags;
+    m.linear = (flags & F_LINEAR) != 0u;
     const bool gauss = (flags & F_GAUSSIAN) != 0u;
-    const bool table_mode = !linear && !gauss;      // rho is one of 256 values
-    const bool imp_coloring = (flags & F_IMP_COLORING) != 0u;
-    const bool imp_rendering = (flags & F_IMP_RENDERING) != 0u;
+    m.table_mode = !m.linear && !gauss;      // rho is one of 256 values
+    const bool use_df = VARIANT == 1 && m.table_mode;
 
     {
         const uint32_t i = threadIdx.x;
         s_tf_tab[i] = tables->tf_tab[i];
         s_rho[i] = tables->rho[i];
-        if (!table_mode) s_lut[i] = tables->lut_f[i];
-        if (imp_coloring) s_ic_alpha[i] = tables->ic_alpha[i];
+        if (!m.table_mode) s_lut[i] = tables->lut_f[i];
+        if (flags & F_IMP_COLORING) s_ic_alpha[i] = tables->ic_alpha[i];
+        if (use_df) {
+            const uint32_t n16 = (fp.mc_n * fp.mc_n * fp.mc_n / 2u + 15u) / 16u;   // 16-byte pieces
+            const uint4* src = reinterpret_cast<const uint4*>(df4);
+            uint4* dst = reinterpret_cast<uint4*>(s_df);
+            for (uint32_t k = i; k < n16; k += 256u) dst[k] = src[k];
+        }
     }
     __syncthreads();
 
@@ -79,63 +174,54 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
         const Ray ray = make_ray(fp, gx, gy);
         if (ray.hit) {
             if (COUNT) n_hit = 1;
-            const V3 eye = ray.o;
             const float base = fp.base_step, min_step = fp.min_step, thr = fp.thr;
             float t = ray.t_entry, cur = base;
             V3 acc = v3(0.0f, 0.0f, 0.0f);
             float acc_a = 0.0f;
 
-            // --- VARIANT 1 state: conservative "no sample in [t, t_safe) can be dense" ---
-            float t_safe = -1.0f;
-            const float mcf = static_cast<float>(fp.mc_n);
-            // reciprocal direction for cell-exit distances (conservative use only, not EXACT)
+            // distance-field leaps: conservative arithmetic only (never decides a pixel by itself)
+            const float mcf = static_cast<float>(fp.mc_n), inv_mc = 1.0f / mcf;
             const float idx_ = 1.0f / ray.d.x, idy_ = 1.0f / ray.d.y, idz_ = 1.0f / ray.d.z;
+            const float nox = -ray.o.x * idx_, noy = -ray.o.y * idy_, noz = -ray.o.z * idz_;
 
             while (t < ray.t_exit && acc_a < 0.95f) {             // wgsl:250
-                if (VARIANT == 1 && table_mode) {
-                    if (t < t_safe) {
-                        // Replay of an empty step: rho < thr is known, so (wgsl:263-274)
-                        // cur = min(base, cur*1.5); t += cur.  Fetches elided.
-                        if (COUNT) { n_steps++; n_vol++; n_imp++; }
-                        cur = __builtin_fminf(base, cur * 1.5f);
-                        t += cur;
-                        continue;
-                    }
-                }
+                if (TRACE) trace_iters++;
                 const V3 pos = ray.o + ray.d * t;                 // wgsl:251
-                if (VARIANT == 1 && table_mode) {
-                    // macro cell of pos; its max byte decides whether the cell can hold a dense voxel
+                if (use_df) {
+                    // Every sample whose position lies in a macro cell with distance value D >= 1 sees
+                    // rho < threshold: the (2D-1)^3 cells around it hold no voxel >= thr_byte.  Such a
+                    // step is (wgsl:263-274) cur = min(base, cur*1.5); t += cur -- replayed here in the
+                    // same f32 arithmetic, without the fetches.
                     const float cxf = __builtin_floorf(pos.x * mcf), cyf = __builtin_floorf(pos.y * mcf),
                                 czf = __builtin_floorf(pos.z * mcf);
-                    const float hi = mcf - 1.0f;
-                    const bool inside = cxf >= 0.0f && cyf >= 0.0f && czf >= 0.0f && cxf <= hi && cyf <= hi && czf <= hi;
-                    if (inside) {
-                        const uint32_t ci = static_cast<uint32_t>(cxf) +
-                                            fp.mc_n * (static_cast<uint32_t>(cyf) + fp.mc_n * static_cast<uint32_t>(czf));
-                        if (static_cast<uint32_t>(mc_max[ci]) < fp.thr_byte) {
-                            // distance along the ray until pos leaves the cell shrunk by eps on every face
-                            const float inv = 1.0f / mcf;
-                            const float eps = 4.0e-5f;
-                            const float x0 = cxf * inv + eps, x1 = (cxf + 1.0f) * inv - eps;
-                            const float y0 = cyf * inv + eps, y1 = (cyf + 1.0f) * inv - eps;
-                            const float z0 = czf * inv + eps, z1 = (czf + 1.0f) * inv - eps;
-                            const bool within = pos.x > x0 && pos.x < x1 && pos.y > y0 && pos.y < y1 && pos.z > z0 && pos.z < z1;
-                            if (within) {
-                                const float ex = ((ray.d.x >= 0.0f ? x1 : x0) - ray.o.x) * idx_;
-                                const float ey = ((ray.d.y >= 0.0f ? y1 : y0) - ray.o.y) * idy_;
-                                const float ez = ((ray.d.z >= 0.0f ? z1 : z0) - ray.o.z) * idz_;
-                                // NaN/inf (d component 0) drop out of fmin; relative slack covers rounding
-                                float te = __builtin_fminf(__builtin_fminf(ex, ey), ez);
-                                te = te - 1.0e-5f * __builtin_fabsf(te);
-                                if (te > t) t_safe = te;
-                            }
-                        }
+                    const int cx = static_cast<int>(cxf), cy = static_cast<int>(cyf), cz = static_cast<int>(czf);
+                    uint32_t D = 0;
+                    if (static_cast<uint32_t>(cx | cy | cz) < fp.mc_n) {
+                        const uint32_t ci = static_cast<uint32_t>(cx) + fp.mc_n * (static_cast<uint32_t>(cy) + fp.mc_n * static_cast<uint32_t>(cz));
+                        D = (static_cast<uint32_t>(s_df[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
                     }
-                    if (t < t_safe) {
-                        if (COUNT) { n_steps++; n_vol++; n_imp++; }
-                        cur = __builtin_fminf(base, cur * 1.5f);
-                        t += cur;
-                        continue;
+                    if (D != 0u) {
+                        // box of empty cells [c-R, c+R+1]/mc_n shrunk by eps on every face, R = D-1
+                        const float eps = 4.0e-5f;
+                        const float a = static_cast<float>(D - 1u) * inv_mc - eps;
+                        const float lx = __builtin_fmaf(cxf, inv_mc, -a), hx = __builtin_fmaf(cxf, inv_mc, a + inv_mc);
+                        const float ly = __builtin_fmaf(cyf, inv_mc, -a), hy = __builtin_fmaf(cyf, inv_mc, a + inv_mc);
+                        const float lz = __builtin_fmaf(czf, inv_mc, -a), hz = __builtin_fmaf(czf, inv_mc, a + inv_mc);
+                        const float ex = __builtin_fmaxf(__builtin_fmaf(lx, idx_, nox), __builtin_fmaf(hx, idx_, nox));
+                        const float ey = __builtin_fmaxf(__builtin_fmaf(ly, idy_, noy), __builtin_fmaf(hy, idy_, noy));
+                        const float ez = __builtin_fmaxf(__builtin_fmaf(lz, idz_, noz), __builtin_fmaf(hz, idz_, noz));
+                        float te = __builtin_fminf(__builtin_fminf(ex, ey), ez);   // NaN (0*inf) drops out
+                        te = te - 2.0e-5f * __builtin_fabsf(te);                    // rounding slack
+                        const bool inside = pos.x > lx && pos.x < hx && pos.y > ly && pos.y < hy && pos.z > lz && pos.z < hz;
+                        const float t_stop = __builtin_fminf(te, ray.t_exit);
+                        if (inside && t < t_stop) {
+                            do {
+                                if (COUNT) { n_steps++; n_vol++; n_imp++; }
+                                cur = __builtin_fminf(base, cur * 1.5f);
+                                t += cur;
+                            } while (t < t_stop);
+                            continue;
+                        }
                     }
                 }
                 if (COUNT) n_steps++;
@@ -145,7 +231,7 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
                 uint32_t off = 0, b = 0;
                 float rho = 0.0f;
                 bool dense;
-                if (table_mode) {
+                if (m.table_mode) {
                     ix = texel_nearest(pos.x, g.fnx, g.hix);
                     iy = texel_nearest(pos.y, g.fny, g.hiy);
                     iz = texel_nearest(pos.z, g.fnz, g.hiz);
@@ -154,8 +240,8 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
                     if (COUNT) n_vol++;
                     dense = b >= fp.thr_byte;                     // <=> b/255 >= thr
                 } else {
-                    if (gauss) rho = sample_density_smoothed<COUNT>(g, s_rho, linear, fp, pos, ray.d, n_vol);
-                    else { rho = sample_density(g, s_rho, linear, pos); if (COUNT) n_vol++; }
+                    if (gauss) rho = sample_density_smoothed<COUNT>(g, s_rho, m.linear, fp, pos, ray.d, n_vol);
+                    else { rho = sample_density(g, s_rho, m.linear, pos); if (COUNT) n_vol++; }
                     dense = rho >= thr;
                     off = nearest_offset(g, pos);                 // importance texel (always nearest)
                 }
@@ -163,69 +249,8 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
                 cur = dense ? min_step : __builtin_fminf(base, cur * 1.5f);
                 if (!dense) { t += cur; continue; }
                 if (COUNT) n_dense++;
-
-                // ---- classification (wgsl:276-304) ----
-                float cr, cg, cb, alpha_step;
-                bool use_alpha = (flags & F_OPACITY) != 0u;
-                if (imp_coloring) {                               // wgsl:83-92
-                    const uint32_t ib = imp[off];
-                    const float im = s_rho[ib];
-                    cr = __builtin_fminf(im * 1.5f, 1.0f);
-                    cg = (1.0f - im) * 1.2f;
-                    cb = 0.2f;
-                    alpha_step = s_ic_alpha[ib];
-                    use_alpha = true;
-                } else {
-                    if (imp_rendering) {                          // wgsl:283-295
-                        const uint32_t ib = imp[off];
-                        const bool ahead = (flags & F_CONE) ? ahead_cone<COUNT>(g, fp, pos, ray.d, ray.t_exit, n_imp)
-                                                            : ahead_straight<COUNT>(g, fp, pos, ray.d, ray.t_exit, n_imp);
-                        if (ib < 255u && ahead) { t += cur; continue; }   // importance < 1.0 && ahead
-                    }
-                    if (table_mode) {
-                        const float4 ca = s_tf_tab[b];
-                        cr = ca.x; cg = ca.y; cb = ca.z; alpha_step = ca.w;
-                    } else {
-                        const float4 ca = sample_tf(s_lut, fp.tf_n, rho);   // wgsl:297-303
-                        cr = ca.x; cg = ca.y; cb = ca.z;
-                        alpha_step = 1.0f - wgsl_pow(1.0f - ca.w, fp.alpha_y);   // wgsl:314
-                    }
-                }
-
-                // ---- gradient taps (wgsl:181-188) ----
-                V3 grad;
-                const float o = 0.01f;
-                if (table_mode) {
-                    const int ixp = texel_nearest(pos.x + o, g.fnx, g.hix), ixm = texel_nearest(pos.x - o, g.fnx, g.hix);
-                    const int iyp = texel_nearest(pos.y + o, g.fny, g.hiy), iym = texel_nearest(pos.y - o, g.fny, g.hiy);
-                    const int izp = texel_nearest(pos.z + o, g.fnz, g.hiz), izm = texel_nearest(pos.z - o, g.fnz, g.hiz);
-                    const uint32_t bxp = vol[voxel_offset(g, ixp, iy, iz)], bxm = vol[voxel_offset(g, ixm, iy, iz)];
-                    const uint32_t byp = vol[voxel_offset(g, ix, iyp, iz)], bym = vol[voxel_offset(g, ix, iym, iz)];
-                    const uint32_t bzp = vol[voxel_offset(g, ix, iy, izp)], bzm = vol[voxel_offset(g, ix, iy, izm)];
-                    grad = v3(s_rho[bxp] - s_rho[bxm], s_rho[byp] - s_rho[bym], s_rho[bzp] - s_rho[bzm]);
-                } else {
-                    grad = v3(sample_density(g, s_rho, linear, v3(pos.x + o, pos.y, pos.z)) -
-                                  sample_density(g, s_rho, linear, v3(pos.x - o, pos.y, pos.z)),
-                              sample_density(g, s_rho, linear, v3(pos.x, pos.y + o, pos.z)) -
-                                  sample_density(g, s_rho, linear, v3(pos.x, pos.y - o, pos.z)),
-                              sample_density(g, s_rho, linear, v3(pos.x, pos.y, pos.z + o)) -
-                                  sample_density(g, s_rho, linear, v3(pos.x, pos.y, pos.z - o)));
-                }
-                if (COUNT) n_vol += 6;
-                // the common 1/(2*0.01) factor cancels in normalize()
-                const V3 shaded = blinn_phong(v3(cr, cg, cb), grad, pos, eye);   // wgsl:306-311
-
-                if (use_alpha) {                                  // wgsl:313-318
-                    const float w = (1.0f - acc_a) * alpha_step;
-                    acc = v3(__builtin_fmaf(shaded.x, w, acc.x), __builtin_fmaf(shaded.y, w, acc.y),
-                             __builtin_fmaf(shaded.z, w, acc.z));
-                    acc_a += w;
-                } else {                                          // wgsl:319-323
-                    acc = shaded;
-                    acc_a = 1.0f;
-                    break;
-                }
-                t += cur;                                         // wgsl:325
+                if (TRACE) trace_dense++;
+                if (dense_sample<COUNT>(m, g, fp, ray, pos, ix, iy, iz, off, b, rho, t, cur, acc, acc_a, n_vol, n_imp)) break;
             }
             out_r = acc.x; out_g = acc.y; out_b = acc.z; out_a = acc_a;
         }
@@ -243,6 +268,14 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
         out_shard[static_cast<size_t>(local_tile) * 256u + threadIdx.x] = 0u;
     }
 
+    if (TRACE) {
+        uint32_t it = trace_iters, dn = trace_dense;
+        for (int s = 32; s > 0; s >>= 1) { it = max(it, __shfl_xor(it, s, 64)); dn = max(dn, __shfl_xor(dn, s, 64)); }
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0)
+            trace[(static_cast<size_t>(blockIdx.x) << 2) | wave] =
+                make_uint4(static_cast<uint32_t>(trace_t0), static_cast<uint32_t>(t1 - trace_t0), it, dn);
+    }
     if (COUNT) {
         unsigned long long v[5] = {n_vol, n_imp, n_steps, n_dense, n_hit};
 #pragma unroll
@@ -258,6 +291,42 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
             atomicAdd(&counters->n_dense, v[3]);
             atomicAdd(&counters->n_hit, v[4]);
         }
+    }
+}
+
+// Chebyshev distance (in cells, capped at 15) from every macro cell to the nearest cell that may
+// hold a voxel >= thr_byte; 0 for such cells.  Cells outside the grid count as empty.  One
+// workgroup, whole grid in LDS; packed two cells per byte (low nibble = even cell).
+__global__ __launch_bounds__(1024) void volym_distance_field_kernel(const uint8_t* __restrict__ mc_max, uint8_t* __restrict__ df4,
+                                                                    uint32_t mc_n, uint32_t thr_byte)
+{
+    __shared__ uint8_t d[32 * 32 * 32];
+    const uint32_t cells = mc_n * mc_n * mc_n;
+    for (uint32_t c = threadIdx.x; c < cells; c += 1024u) d[c] = mc_max[c] >= thr_byte ? 0 : 15;
+    __syncthreads();
+    // D(c) = min(D(c), 1 + min over the 26 neighbours): values only decrease and never drop below
+    // the true distance, so in-place relaxation is safe; 14 sweeps reach every distance <= 15.
+    for (int sweep = 0; sweep < 14; ++sweep) {
+        for (uint32_t c = threadIdx.x; c < cells; c += 1024u) {
+            const int x = static_cast<int>(c % mc_n), y = static_cast<int>((c / mc_n) % mc_n), z = static_cast<int>(c / (mc_n * mc_n));
+            uint32_t best = d[c];
+            if (best > 1u) {
+                for (int dz = -1; dz <= 1; ++dz)
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int xx = x + dx, yy = y + dy, zz = z + dz;
+                            if (xx < 0 || yy < 0 || zz < 0 || xx >= static_cast<int>(mc_n) || yy >= static_cast<int>(mc_n) || zz >= static_cast<int>(mc_n)) continue;
+                            const uint32_t v = d[static_cast<uint32_t>(xx) + mc_n * (static_cast<uint32_t>(yy) + mc_n * static_cast<uint32_t>(zz))] + 1u;
+                            best = v < best ? v : best;
+                        }
+                d[c] = static_cast<uint8_t>(best);
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t k = threadIdx.x; k < (cells + 1u) / 2u; k += 1024u) {
+        const uint32_t lo = d[2u * k], hi = 2u * k + 1u < cells ? d[2u * k + 1u] : 0u;
+        df4[k] = static_cast<uint8_t>(lo | (hi << 4));
     }
 }
 

@@ -1,0 +1,363 @@
+// VARIANT 2 of the ray-march: persistent workgroups + per-wave shading queue (gfx950).
+//
+// Why this shape (profiles/ and DESIGN.md "Kernel v2"): with one pixel per lane and a monolithic
+// loop, the kernel time was the latency of its longest rays -- ~80 dependent iterations of
+// {byte gather -> classify -> 6 gradient gathers -> Blinn-Phong -> composite}, executed by waves in
+// which a handful of lanes were still alive.  Three observations remove that chain:
+//
+//  1. CONTROL needs one byte per sample.  Positions, the step state machine, rho >= threshold, the
+//     opacity alpha_step (a table of the byte), the alpha < 0.95 exit: none of it needs the gradient
+//     or the shading.  So a lane runs only the control path, and every dense sample it accepts is
+//     pushed into a per-wave LDS queue as {pos, weight w = (1-alpha)*alpha_step, class byte, owner}.
+//  2. COLOUR is a sum of independent terms w_k * shade(pos_k).  Whenever 64 samples are queued the
+//     whole wave shades them, one sample per lane, whoever owns them, and adds the result to the
+//     owner's accumulator in LDS.  The accumulators are 4.28 fixed point and are updated with integer
+//     atomics, so the sum is independent of the order of arrival: deterministic and identical on
+//     every GPU/sharding.  (|error| <= 4e-9 per term; the budget is 1e-4.)
+//  3. The control path itself is speculated K samples at a time: predict that the next K samples
+//     have the class (dense / not dense) of the last one, which fixes their positions through the
+//     step state machine; issue the K byte gathers together; then accept samples in order with the
+//     REAL classes and stop at the first misprediction.  Accepted samples are bit-identical to the
+//     sequential march (same f32 operations in the same order).
+//
+// Work distribution: persistent workgroups of 8 waves; the 8x8-pixel wave tiles of this rank are
+// sorted centre-first on the host (the orbit camera always targets the volume centre, src/camera.rs:23,
+// so the expensive tiles are the central ones) and wave g takes items g, g+G, g+2G, ...: the long
+// rays start first and the cheap border tiles fill in behind them.  No atomics, no inter-workgroup
+// communication.
+#pragma once
+
+#include "raymarch_device.h"
+
+namespace volym {
+
+constexpr int PQ_WAVES = 8;              // waves per workgroup
+constexpr int PQ_THREADS = PQ_WAVES * 64;
+constexpr int PQ_QCAP = 128;             // ring entries per wave (>= 64 queued + 64 new)
+constexpr float PQ_FIX_SCALE = 268435456.0f;        // 2^28
+constexpr float PQ_FIX_INV = 1.0f / 268435456.0f;
+
+__device__ __forceinline__ uint32_t lane_rank_in_mask(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+template <bool TABLE, bool COUNT>
+__global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
+    const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
+    const uint8_t* __restrict__ df4, const uint32_t* __restrict__ order, uint32_t n_items, uint32_t* __restrict__ out_shard,
+    uint32_t* __restrict__ out_raster, float4* __restrict__ out_f32, Counters* __restrict__ counters, const FrameParams fp)
+{
+    constexpr int K = TABLE ? 4 : 1;     // speculation depth
+
+    __shared__ float4 s_tf_tab[256];
+    __shared__ float4 s_lut[TABLE ? 1 : 256];
+    __shared__ float s_ic_alpha[256];
+    __shared__ float s_rho[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_df[TABLE ? VOLYM_DF_LDS_BYTES : 16];
+    __shared__ float s_qx[PQ_WAVES][PQ_QCAP], s_qy[PQ_WAVES][PQ_QCAP], s_qz[PQ_WAVES][PQ_QCAP], s_qw[PQ_WAVES][PQ_QCAP];
+    __shared__ uint32_t s_qm[PQ_WAVES][PQ_QCAP];
+    __shared__ float s_qr[TABLE ? 1 : PQ_WAVES][TABLE ? 1 : PQ_QCAP];
+    __shared__ uint32_t s_acc[PQ_WAVES][3][64];
+
+    const uint32_t flags = fp.flags;
+    const bool linear = (flags & F_LINEAR) != 0u;
+    const bool gauss = (flags & F_GAUSSIAN) != 0u;
+    const bool imp_coloring = (flags & F_IMP_COLORING) != 0u;
+    const bool imp_rendering = (flags & F_IMP_RENDERING) != 0u;
+    const bool need_imp = imp_coloring || imp_rendering;
+
+    {
+        const uint32_t i = threadIdx.x;
+        if (i < 256u) {
+            s_tf_tab[i] = tables->tf_tab[i];
+            s_rho[i] = tables->rho[i];
+            s_ic_alpha[i] = tables->ic_alpha[i];
+            if (!TABLE) s_lut[i] = tables->lut_f[i];
+        }
+        if (TABLE) {
+            const uint32_t n16 = (fp.mc_n * fp.mc_n * fp.mc_n / 2u + 15u) / 16u;
+            const uint4* src = reinterpret_cast<const uint4*>(df4);
+            uint4* dst = reinterpret_cast<uint4*>(s_df);
+            for (uint32_t k = i; k < n16; k += PQ_THREADS) dst[k] = src[k];
+        }
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t total_waves = gridDim.x * PQ_WAVES;
+
+    Grid g;
+    g.vol = vol; g.imp = imp;
+    g.nx = static_cast<int>(fp.nx); g.ny = static_cast<int>(fp.ny); g.nz = static_cast<int>(fp.nz);
+    g.fnx = static_cast<float>(fp.nx); g.fny = static_cast<float>(fp.ny); g.fnz = static_cast<float>(fp.nz);
+    g.hix = static_cast<float>(fp.nx - 1u); g.hiy = static_cast<float>(fp.ny - 1u); g.hiz = static_cast<float>(fp.nz - 1u);
+
+    float* const qx = s_qx[wave];
+    float* const qy = s_qy[wave];
+    float* const qz = s_qz[wave];
+    float* const qw = s_qw[wave];
+    uint32_t* const qm = s_qm[wave];
+    float* const qr = s_qr[TABLE ? 0 : wave];
+    uint32_t* const acc_r = s_acc[wave][0];
+    uint32_t* const acc_g = s_acc[wave][1];
+    uint32_t* const acc_b = s_acc[wave][2];
+
+    uint32_t n_vol = 0, n_imp = 0, n_steps = 0, n_dense = 0, n_hit = 0;
+    const V3 eye = v3(fp.eye[0], fp.eye[1], fp.eye[2]);
+    const float base = fp.base_step, min_step = fp.min_step, thr = fp.thr;
+    const float mcf = static_cast<float>(fp.mc_n), inv_mc = 1.0f / mcf;
+
+    for (uint32_t item_idx = blockIdx.x * PQ_WAVES + wave; item_idx < n_items; item_idx += total_waves) {
+        const uint32_t item = __builtin_amdgcn_readfirstlane(order[item_idx]);
+        const uint32_t local_tile = item >> 2, sub = item & 3u;
+        const uint32_t tile = local_tile * fp.world + fp.rank;
+        const uint32_t tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
+        const uint32_t gx = tx * 16u + ((sub & 1u) << 3) + (lane & 7u);
+        const uint32_t gy = ty * 16u + ((sub >> 1) << 3) + (lane >> 3);
+        const bool in_frame = gx < fp.W && gy < fp.H;   // wgsl:217-219
+
+        acc_r[lane] = 0u; acc_g[lane] = 0u; acc_b[lane] = 0u;
+        uint32_t q_head = 0, q_count = 0;               // wave-uniform ring state
+
+        Ray ray;
+        ray.hit = false;
+        if (in_frame) ray = make_ray(fp, gx, gy);
+        bool active = in_frame && ray.hit;
+        if (COUNT && active) n_hit++;
+        float t = active ? ray.t_entry : 0.0f, cur = base, acc_a = active ? 0.0f : 1.0f;   // miss: (0,0,0,1) wgsl:239
+        bool last_dense = false;
+        const float idx_ = 1.0f / ray.d.x, idy_ = 1.0f / ray.d.y, idz_ = 1.0f / ray.d.z;
+        const float nox = -ray.o.x * idx_, noy = -ray.o.y * idy_, noz = -ray.o.z * idz_;
+
+        // ---- shade up to 64 queued samples, one per lane (COLOUR arithmetic) ----
+        auto flush = [&](uint32_t n) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < n) {
+                const uint32_t e = (q_head + lane) & (PQ_QCAP - 1);
+                const V3 pos = v3(qx[e], qy[e], qz[e]);
+                const float w = qw[e];
+                const uint32_t meta = qm[e];
+                const uint32_t owner = meta & 63u, b = (meta >> 8) & 255u, ib = (meta >> 16) & 255u;
+                V3 color;
+                if (imp_coloring) {                                   // wgsl:83-92
+                    const float im = s_rho[ib];
+                    color = v3(__builtin_fminf(im * 1.5f, 1.0f), (1.0f - im) * 1.2f, 0.2f);
+                } else if (TABLE) {
+                    const float4 ca = s_tf_tab[b];
+                    color = v3(ca.x, ca.y, ca.z);
+                } else {
+                    const float4 ca = sample_tf(s_lut, fp.tf_n, qr[e]); // wgsl:297-303
+                    color = v3(ca.x, ca.y, ca.z);
+                }
+                // gradient taps (wgsl:181-188); the common 1/(2*0.01) factor cancels in normalize()
+                V3 grad;
+                const float o = 0.01f;
+                if (TABLE) {
+                    const int ix = texel_nearest(pos.x, g.fnx, g.hix), iy = texel_nearest(pos.y, g.fny, g.hiy),
+                              iz = texel_nearest(pos.z, g.fnz, g.hiz);
+                    const int ixp = texel_nearest(pos.x + o, g.fnx, g.hix), ixm = texel_nearest(pos.x - o, g.fnx, g.hix);
+                    const int iyp = texel_nearest(pos.y + o, g.fny, g.hiy), iym = texel_nearest(pos.y - o, g.fny, g.hiy);
+                    const int izp = texel_nearest(pos.z + o, g.fnz, g.hiz), izm = texel_nearest(pos.z - o, g.fnz, g.hiz);
+                    const int bxp = vol[voxel_offset(g, ixp, iy, iz)], bxm = vol[voxel_offset(g, ixm, iy, iz)];
+                    const int byp = vol[voxel_offset(g, ix, iyp, iz)], bym = vol[voxel_offset(g, ix, iym, iz)];
+                    const int bzp = vol[voxel_offset(g, ix, iy, izp)], bzm = vol[voxel_offset(g, ix, iy, izm)];
+                    // b/255 differences up to the common factor 1/255
+                    grad = v3(static_cast<float>(bxp - bxm), static_cast<float>(byp - bym), static_cast<float>(bzp - bzm));
+                } else {
+                    grad = v3(sample_density(g, s_rho, linear, v3(pos.x + o, pos.y, pos.z)) -
+                                  sample_density(g, s_rho, linear, v3(pos.x - o, pos.y, pos.z)),
+                              sample_density(g, s_rho, linear, v3(pos.x, pos.y + o, pos.z)) -
+                                  sample_density(g, s_rho, linear, v3(pos.x, pos.y - o, pos.z)),
+                              sample_density(g, s_rho, linear, v3(pos.x, pos.y, pos.z + o)) -
+                                  sample_density(g, s_rho, linear, v3(pos.x, pos.y, pos.z - o)));
+                }
+                const V3 shaded = blinn_phong(color, grad, pos, eye);   // wgsl:306-311
+                // w * shaded in 4.28 fixed point; integer adds commute, so arrival order is irrelevant
+                atomicAdd(&acc_r[owner], static_cast<uint32_t>(__builtin_fmaf(shaded.x * w, PQ_FIX_SCALE, 0.5f)));
+                atomicAdd(&acc_g[owner], static_cast<uint32_t>(__builtin_fmaf(shaded.y * w, PQ_FIX_SCALE, 0.5f)));
+                atomicAdd(&acc_b[owner], static_cast<uint32_t>(__builtin_fmaf(shaded.z * w, PQ_FIX_SCALE, 0.5f)));
+            }
+            q_head = (q_head + n) & (PQ_QCAP - 1);
+            q_count -= n;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+
+        // ---- push the samples flagged by `emit` (any subset of lanes), shade when 64 are waiting ----
+        auto append = [&](bool emit, V3 p, float w, uint32_t meta, float rho) {
+            const unsigned long long mask = __ballot(emit);
+            if (mask == 0ull) return;
+            if (emit) {
+                const uint32_t e = (q_head + q_count + lane_rank_in_mask(mask)) & (PQ_QCAP - 1);
+                qx[e] = p.x; qy[e] = p.y; qz[e] = p.z; qw[e] = w; qm[e] = meta;
+                if (!TABLE) qr[e] = rho;
+            }
+            q_count += static_cast<uint32_t>(__popcll(mask));
+            if (q_count >= 64u) flush(64u);
+        };
+
+        while (__ballot(active) != 0ull) {
+            // ---- 1. leap through provably empty macro cells (see raymarch_kernels.h VARIANT 1) ----
+            if (TABLE && active) {
+                for (;;) {
+                    if (!(t < ray.t_exit && acc_a < 0.95f)) { active = false; break; }   // wgsl:250
+                    const V3 pos = ray.o + ray.d * t;
+                    const float cxf = __builtin_floorf(pos.x * mcf), cyf = __builtin_floorf(pos.y * mcf), czf = __builtin_floorf(pos.z * mcf);
+                    const int cx = static_cast<int>(cxf), cy = static_cast<int>(cyf), cz = static_cast<int>(czf);
+                    uint32_t D = 0;
+                    if (static_cast<uint32_t>(cx | cy | cz) < fp.mc_n) {
+                        const uint32_t ci = static_cast<uint32_t>(cx) + fp.mc_n * (static_cast<uint32_t>(cy) + fp.mc_n * static_cast<uint32_t>(cz));
+                        D = (static_cast<uint32_t>(s_df[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
+                    }
+                    if (D == 0u) break;
+                    const float eps = 4.0e-5f;
+                    const float a = static_cast<float>(D - 1u) * inv_mc - eps;
+                    const float lx = __builtin_fmaf(cxf, inv_mc, -a), hx = __builtin_fmaf(cxf, inv_mc, a + inv_mc);
+                    const float ly = __builtin_fmaf(cyf, inv_mc, -a), hy = __builtin_fmaf(cyf, inv_mc, a + inv_mc);
+                    const float lz = __builtin_fmaf(czf, inv_mc, -a), hz = __builtin_fmaf(czf, inv_mc, a + inv_mc);
+                    const float ex = __builtin_fmaxf(__builtin_fmaf(lx, idx_, nox), __builtin_fmaf(hx, idx_, nox));
+                    const float ey = __builtin_fmaxf(__builtin_fmaf(ly, idy_, noy), __builtin_fmaf(hy, idy_, noy));
+                    const float ez = __builtin_fmaxf(__builtin_fmaf(lz, idz_, noz), __builtin_fmaf(hz, idz_, noz));
+                    float te = __builtin_fminf(__builtin_fminf(ex, ey), ez);
+                    te = te - 2.0e-5f * __builtin_fabsf(te);
+                    const bool inside = pos.x > lx && pos.x < hx && pos.y > ly && pos.y < hy && pos.z > lz && pos.z < hz;
+                    const float t_stop = __builtin_fminf(te, ray.t_exit);
+                    if (!(inside && t < t_stop)) break;
+                    do {                                          // replay of empty steps, wgsl:263-274
+                        if (COUNT) { n_steps++; n_vol++; n_imp++; }
+                        cur = __builtin_fminf(base, cur * 1.5f);
+                        t += cur;
+                    } while (t < t_stop);
+                    last_dense = false;
+                }
+            }
+
+            // ---- 2. K speculative samples: positions under the prediction "class stays last_dense" ----
+            float ts[K];
+            uint32_t offs[K], bs[K], ibs[K];
+            float rhos[K];
+            {
+                float tt = t, cc = cur;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    ts[k] = tt;
+                    const V3 p = ray.o + ray.d * tt;              // wgsl:251
+                    offs[k] = nearest_offset(g, p);
+                    cc = last_dense ? min_step : __builtin_fminf(base, cc * 1.5f);
+                    tt += cc;
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    bs[k] = 0; ibs[k] = 0; rhos[k] = 0.0f;
+                    if (active) {
+                        if (TABLE) bs[k] = vol[offs[k]];
+                        if (need_imp) ibs[k] = imp[offs[k]];
+                    }
+                }
+            }
+
+            // ---- 3. accept samples in order with their real classes ----
+            bool valid = active;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                bool emit = false;
+                V3 pos = v3(0.0f, 0.0f, 0.0f);
+                float w = 0.0f;
+                if (valid && !(t < ray.t_exit && acc_a < 0.95f)) { active = false; valid = false; }   // wgsl:250
+                if (valid) {
+                    if (COUNT) { n_steps++; n_imp++; }            // wgsl:260 fetches importance every step
+                    pos = ray.o + ray.d * t;                      // t == ts[k] bit for bit while valid
+                    bool dense;
+                    if (TABLE) {
+                        if (COUNT) n_vol++;
+                        dense = bs[k] >= fp.thr_byte;             // <=> b/255 >= thr
+                    } else {
+                        if (gauss) rhos[k] = sample_density_smoothed<COUNT>(g, s_rho, linear, fp, pos, ray.d, n_vol);
+                        else { rhos[k] = sample_density(g, s_rho, linear, pos); if (COUNT) n_vol++; }
+                        dense = rhos[k] >= thr;
+                    }
+                    const bool predicted = last_dense;
+                    cur = dense ? min_step : __builtin_fminf(base, cur * 1.5f);   // wgsl:263-269
+                    last_dense = dense;
+                    if (dense != predicted) valid = false;        // later speculative positions are off
+                    bool advance = true;
+                    if (dense) {
+                        if (COUNT) n_dense++;
+                        bool use_alpha = (flags & F_OPACITY) != 0u;
+                        float alpha_step;
+                        bool suppressed = false;
+                        if (imp_coloring) {
+                            alpha_step = s_ic_alpha[ibs[k]];
+                            use_alpha = true;                     // wgsl:279-281
+                        } else {
+                            if (imp_rendering) {                  // wgsl:283-295
+                                const bool ahead = (flags & F_CONE) ? ahead_cone<COUNT>(g, fp, pos, ray.d, ray.t_exit, n_imp)
+                                                                    : ahead_straight<COUNT>(g, fp, pos, ray.d, ray.t_exit, n_imp);
+                                suppressed = ibs[k] < 255u && ahead;
+                            }
+                            if (TABLE) alpha_step = s_tf_tab[bs[k]].w;
+                            else alpha_step = 1.0f - wgsl_pow(1.0f - sample_tf(s_lut, fp.tf_n, rhos[k]).w, fp.alpha_y);   // wgsl:314
+                        }
+                        if (!suppressed) {
+                            if (COUNT) n_vol += 6;                // the six gradient taps, wgsl:181-188
+                            emit = true;
+                            if (use_alpha) {                      // wgsl:313-318
+                                w = (1.0f - acc_a) * alpha_step;
+                                acc_a += w;
+                            } else {                              // wgsl:319-323: first hit, break
+                                w = 1.0f;
+                                acc_a = 1.0f;
+                                advance = false;
+                                active = false;
+                                valid = false;
+                            }
+                        }
+                    }
+                    if (advance) t += cur;                        // wgsl:272, :292, :325
+                }
+                append(emit, pos, w, lane | (bs[k] << 8) | (ibs[k] << 16), rhos[k]);
+            }
+        }
+        if (q_count) flush(q_count);
+
+        // ---- store (wgsl:328-329; rgba8unorm) ----
+        if (in_frame) {
+            const float out_r = static_cast<float>(acc_r[lane]) * PQ_FIX_INV, out_g = static_cast<float>(acc_g[lane]) * PQ_FIX_INV,
+                        out_b = static_cast<float>(acc_b[lane]) * PQ_FIX_INV;
+            const uint32_t packed = pack_rgba8(out_r, out_g, out_b, acc_a);
+            if (flags & F_RASTER) {
+                const size_t o = static_cast<size_t>(gy) * fp.W + gx;
+                out_raster[o] = packed;
+                if (flags & F_WRITE_F32) out_f32[o] = make_float4(out_r, out_g, out_b, acc_a);
+            } else {
+                out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + lane] = packed;
+            }
+        } else if (!(flags & F_RASTER)) {
+            out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + lane] = 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (COUNT) {
+        unsigned long long v[5] = {n_vol, n_imp, n_steps, n_dense, n_hit};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            unsigned long long x = v[k];
+            for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s, 64);
+            v[k] = x;
+        }
+        if (lane == 0) {
+            atomicAdd(&counters->n_vol, v[0]);
+            atomicAdd(&counters->n_imp, v[1]);
+            atomicAdd(&counters->n_steps, v[2]);
+            atomicAdd(&counters->n_dense, v[3]);
+            atomicAdd(&counters->n_hit, v[4]);
+        }
+    }
+}
+
+}  // namespace volym
