@@ -26,6 +26,11 @@ def main():
     ap.add_argument("--kernels", type=int, nargs="*", default=[0, 1])
     ap.add_argument("--cases", nargs="*", default=["bench", "miss", "empty", "solid"])
     ap.add_argument("--step", type=float, default=0.01)
+    ap.add_argument("--wgs", type=int, nargs="*", default=[2])
+    ap.add_argument("--kspec", type=int, nargs="*", default=[4])
+    ap.add_argument("--cull", type=int, nargs="*", default=[1])
+    ap.add_argument("--noshade", type=int, default=0)
+    ap.add_argument("--feedback", type=int, nargs="*", default=[1])
     args = ap.parse_args()
     W, H = args.width, args.height
     dims = (256, 256, 256)
@@ -49,15 +54,20 @@ def main():
             v, cu = cases[name]
             ctx.set_volume(v, dims)
             for k in args.kernels:
-                for b in args.bands:
+                for b, ks, cl, fb in [(b, ks, cl, fb) for b in (args.bands if k != 2 else args.wgs) for ks in (args.kspec if k == 2 else [1]) for cl in (args.cull if k == 2 else [1]) for fb in (args.feedback if k == 2 else [0])]:
+                    ctx.set_option(102, ks)
+                    ctx.set_option(103, cl)
+                    ctx.set_option(104, fb)
+                    if k == 2:
+                        ctx.set_option(_lib.OPT_XCD_BANDS, 0x100 if args.noshade else 0)
                     ctx.set_option(_lib.OPT_KERNEL, k)
-                    ctx.set_option(_lib.OPT_XCD_BANDS, b)
+                    ctx.set_option(_lib.OPT_XCD_BANDS if k != 2 else 101, b)
                     ctx.update(cu, pu)
                     ctx.time_passes(5)
                     ms = ctx.time_passes(args.n)
                     st = ctx.stats_pass()
-                    print("%-6s kernel %d bands %2d: %8.1f us (min %7.1f)  steps %10d dense %9d hit %8d" %
-                          (name, k, b, 1e3 * float(np.mean(ms)), 1e3 * float(ms.min()), st["n_steps"], st["n_dense"], st["n_hit"]), flush=True)
+                    print("%-6s kernel %d K%d cull%d fb%d bands %2d: %8.1f us (min %7.1f)  steps %10d dense %9d hit %8d" %
+                          (name, k, ks, cl, fb, b, 1e3 * float(np.mean(ms)), 1e3 * float(ms.min()), st["n_steps"], st["n_dense"], st["n_hit"]), flush=True)
 
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@ def main():
         ctx.set_importances(np.zeros(256 ** 3, np.uint8), dims)
         ctx.set_transfer_function(scene.default_lut())
         ctx.set_option(_lib.OPT_KERNEL, args.kernel)
-        ctx.set_option(_lib.OPT_XCD_BANDS, args.bands)
+        ctx.set_option(_lib.OPT_XCD_BANDS if args.kernel != 2 else 101, args.bands if args.kernel != 2 else max(args.bands, 1))
         ctx.update(state.camera_uniforms(), state.parameter_uniforms())
         ctx.stats_pass()
         nrec = (ctx.local_tiles() + 64) * 8
@@ -46,7 +46,12 @@ def main():
         print("host wall of the traced launch incl. memset+copy: %.1f us" % ((t_b - t_a) * 1e6))
         t_a = time.perf_counter(); ctx.stats_pass(); t_b = time.perf_counter()
         print("host wall of stats_pass: %.1f us ; event-timed plain pass %.1f us" % ((t_b - t_a) * 1e6, 1e3 * float(ctx.time_passes(20).mean())))
-    r = buf[: ctx.local_tiles() * 4] if False else buf[:8160 * 4]
+    r = buf[:8160 * 4 + 20480]
+    ph = None
+    if args.kernel == 2:
+        ph = r[1:2 * 5120 * 2:2]
+        r = r[0:2 * 5120 * 2:2]
+        ph = ph[r[:, 1] > 0]
     r = r[r[:, 1] > 0]
     t0 = r[:, 0].astype(np.int64)
     t0 = (t0 - t0.min()) & 0xFFFFFFFF
@@ -56,21 +61,33 @@ def main():
     print("wave duration us: mean %.2f  p50 %.2f  p90 %.2f  p99 %.2f  max %.2f" % (
         dur.mean() / 100, np.percentile(dur, 50) / 100, np.percentile(dur, 90) / 100, np.percentile(dur, 99) / 100, dur.max() / 100))
     print("sum of wave durations %.1f us-waves => mean resident waves %.1f" % (dur.sum() / 100, dur.sum() / max(end.max(), 1)))
-    print("start time us: p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(t0, q) / 100 for q in (50, 90, 99, 100)))
-    it = r[:, 2]
-    dn = r[:, 3]
-    print("iterations/wave (max lane): mean %.1f p90 %d max %d ; dense/wave (max lane): mean %.1f p90 %d max %d" % (
-        it.mean(), np.percentile(it, 90), it.max(), dn.mean(), np.percentile(dn, 90), dn.max()))
-    heavy = dn > 0
-    print("waves with dense samples: %d ; their duration mean %.2f us max %.2f ; us per iteration %.3f" % (
-        heavy.sum(), dur[heavy].mean() / 100, dur[heavy].max() / 100, (dur[heavy] / np.maximum(it[heavy], 1)).mean() / 100))
-    # occupancy timeline in 5 us bins
-    w = max(int(end.max() // 20), 1)
+    print("end time us: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(end, q) / 100 for q in (10, 50, 90, 99, 100)))
+    if args.kernel == 2:
+        iters, tiles = r[:, 2] & 0xFFFF, r[:, 2] >> 16
+        flushes, marched = r[:, 3] & 0xFFFF, r[:, 3] >> 16
+        print("per wave: tiles mean %.1f max %d ; marched tiles mean %.2f max %d ; loop iterations mean %.1f max %d ; flushes mean %.1f max %d" % (
+            tiles.mean(), tiles.max(), marched.mean(), marched.max(), iters.mean(), iters.max(), flushes.mean(), flushes.max()))
+        print("totals: tiles %d marched %d iterations %d flushes %d" % (tiles.sum(), marched.sum(), iters.sum(), flushes.sum()))
+        print("us per loop iteration (waves with >=10 iterations): %.3f" % ((dur[iters >= 10] / iters[iters >= 10]).mean() / 100))
+        tick = ph.astype(np.float64) * 16.0          # shader clock ticks
+        tot = tick.sum(axis=0)
+        print("phase shares over all waves (shader ticks): leap %.1f%%  sample %.1f%%  flush %.1f%%  setup+store %.1f%%  ; ticks per us of wave time: %.0f" % (
+            *(100.0 * tot / tot.sum()), tot.sum() / (dur.sum() / 100.0)))
+        slow = np.argsort(dur)[-16:]
+        ts = tick[slow].sum(axis=0)
+        print("slowest 16 waves: leap %.1f%% sample %.1f%% flush %.1f%% setup %.1f%% ; iterations %s ; dur us %s" % (
+            *(100.0 * ts / ts.sum()), list(iters[slow]), [round(float(x) / 100, 1) for x in dur[slow]]))
+        print("slowest 16: ticks per iteration: leap %.0f sample %.0f flush %.0f" % (
+            tick[slow, 0].sum() / iters[slow].sum(), tick[slow, 1].sum() / iters[slow].sum(), tick[slow, 2].sum() / iters[slow].sum()))
+        # per workgroup (16 waves): end time spread
+        wg_end = end[: len(end) // 16 * 16].reshape(-1, 16).max(axis=1)
+        print("workgroup end us: min %.1f p50 %.1f p90 %.1f max %.1f" % (wg_end.min() / 100, np.percentile(wg_end, 50) / 100, np.percentile(wg_end, 90) / 100, wg_end.max() / 100))
+    else:
+        it, dn = r[:, 2], r[:, 3]
+        print("iterations/wave (max lane): mean %.1f p90 %d max %d ; dense/wave (max lane): mean %.1f max %d" % (it.mean(), np.percentile(it, 90), it.max(), dn.mean(), dn.max()))
+    w = max(int(end.max() // 16), 1)
     bins = np.arange(0, end.max() + w, w)
-    occ = [(round(b / 100, 1), int(((t0 < b + w) & (end > b)).sum())) for b in bins]
-    print("resident waves per bin:", occ)
-    late = np.argsort(end)[-8:]
-    print("last finishers: (start us, dur us, iters, dense)", [(t0[i] / 100, dur[i] / 100, int(it[i]), int(dn[i])) for i in late])
+    print("resident waves per bin:", [(round(float(b) / 100, 1), int(((t0 < b + w) & (end > b)).sum())) for b in bins])
 
 
 if __name__ == "__main__":

@@ -51,6 +51,7 @@ struct volym_ctx {
     uint8_t* d_df = nullptr;   // packed 4-bit distance field for (d_mc, thr_byte)
     uint32_t mc_n = 32, mc_built_n = 0;
     uint32_t df_thr_byte = 0xffffffffu;
+    uint32_t thr_byte_cull = 256;   // threshold byte the macro-cell occupancy is built for (conservative in continuous modes)
     bool mc_dirty = true;
 
     uint32_t* d_shard_own = nullptr;
@@ -62,11 +63,23 @@ struct volym_ctx {
     size_t gather_tmp_bytes = 0;
     Counters* d_counters = nullptr;
     uint4* d_trace = nullptr;   // development aid, see volym_dev_wave_trace
-    uint32_t* d_order = nullptr;   // variant 2: this rank's 8x8 wave tiles, centre-first
+    uint32_t* d_order = nullptr;   // variant 2: this rank's 8x8 wave tiles, centre-first (or by measured cost)
+    std::vector<uint32_t> h_order;   // the geometric (centre-first) list, kept for re-sorting
+    uint16_t* d_cost = nullptr;    // per item: cost the last plain launch measured (loop iterations, flushes)
+    uint32_t frames_since_change = 0;
+    bool order_by_cost = false;    // d_order currently reflects measured cost
+    bool feedback = true;
     uint32_t n_items = 0;
     bool order_dirty = true;
     int n_cus = 256;
-    uint32_t wgs_per_cu = 2;
+    uint32_t wgs_per_cu = 1;
+    int kspec = 4;
+    bool culling = true;
+    int* d_aabb = nullptr;          // occupied macro cells: {xmin, ymin, zmin, xmax, ymax, zmax}
+    int h_aabb[6] = {0, 0, 0, -1, -1, -1};
+    bool hull_dirty = true;
+    volym_camera_uniforms cam_copy;
+    volym_parameter_uniforms par_copy;
 
     FrameParams fp;
     int kernel_variant = 2;
@@ -89,6 +102,13 @@ static int fail(volym_ctx* c, int code, const std::string& msg)
         if (e_ != hipSuccess)                                                                  \
             return fail(ctx, VOLYM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// anything that changes what a tile costs: measured costs no longer apply
+static void invalidate_costs(volym_ctx* c)
+{
+    c->frames_since_change = 0;
+    if (c->order_by_cost) c->order_dirty = true;
+}
 
 static void recompute_shard(volym_ctx* c)
 {
@@ -147,6 +167,8 @@ int volym_create(volym_ctx** out, uint32_t width, uint32_t height, int device_id
     if ((e = hipMalloc(&c->d_tables, sizeof(FrameTables))) != hipSuccess) return bail(e, "hipMalloc(tables)");
     if ((e = hipMalloc(&c->d_counters, sizeof(Counters))) != hipSuccess) return bail(e, "hipMalloc(counters)");
     if ((e = hipMemset(c->d_frame_own, 0, frame_bytes)) != hipSuccess) return bail(e, "hipMemset(frame)");
+    if ((e = hipMalloc(&c->d_aabb, 6 * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(aabb)");
+
     c->d_frame = c->d_frame_own;
     c->d_shard = c->d_shard_own;
     *out = c;
@@ -160,7 +182,7 @@ void volym_destroy(volym_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_vol); (void)hipFree(c->d_imp); (void)hipFree(c->d_tables); (void)hipFree(c->d_mc); (void)hipFree(c->d_df);
     (void)hipFree(c->d_shard_own); (void)hipFree(c->d_frame_own); (void)hipFree(c->d_f32);
-    (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_counters); (void)hipFree(c->d_order);
+    (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_counters); (void)hipFree(c->d_order); (void)hipFree(c->d_cost); (void)hipFree(c->d_aabb);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -177,6 +199,7 @@ int volym_set_stream(volym_ctx* c, void* hip_stream)
 int volym_set_option(volym_ctx* c, int key, int value)
 {
     if (!c) return VOLYM_E_INVALID;
+    invalidate_costs(c);
     switch (key) {
     case VOLYM_OPT_KERNEL:
         if (value < 0 || value > 2) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_KERNEL: 0 (direct), 1 (macro-cell) or 2 (persistent + shading queue)");
@@ -195,8 +218,20 @@ int volym_set_option(volym_ctx* c, int key, int value)
         if (value < 1 || value > 8) return fail(c, VOLYM_E_INVALID, "workgroups per CU: 1..8");
         c->wgs_per_cu = static_cast<uint32_t>(value);
         return VOLYM_OK;
+    case 102:   // undocumented tuning knob: speculation depth of variant 2 (1, 2 or 4)
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, VOLYM_E_INVALID, "speculation depth: 1, 2, 4 or 8");
+        c->kspec = value;
+        return VOLYM_OK;
+    case 104:   // undocumented: 0 disables the cost-feedback reordering of variant 2 (A/B tests)
+        c->feedback = value != 0;
+        c->order_dirty = true;
+        return VOLYM_OK;
+    case 103:   // undocumented: 0 disables the exact culling of variant 2 (A/B tests)
+        c->culling = value != 0;
+        c->hull_dirty = true;
+        return VOLYM_OK;
     case 100:   // undocumented tuning knob: block->tile remap bands per XCD (0 = identity)
-        if (value < 0 || value > 64) return fail(c, VOLYM_E_INVALID, "xcd bands: 0..64");
+        if (value < 0 || value > 0x1ff) return fail(c, VOLYM_E_INVALID, "xcd bands: 0..64 (+0x100 dev bit)");
         c->xcd_bands = static_cast<uint32_t>(value);
         return VOLYM_OK;
     default:
@@ -239,6 +274,7 @@ int volym_set_volume(volym_ctx* c, const uint8_t* voxels, uint32_t nx, uint32_t 
     c->nx = nx; c->ny = ny; c->nz = nz; c->filter = filter;
     c->have_vol = true;
     c->mc_dirty = true;
+    invalidate_costs(c);
     return VOLYM_OK;
 }
 
@@ -249,6 +285,7 @@ int volym_set_importances(volym_ctx* c, const uint8_t* importances, uint32_t nx,
     if (rc != VOLYM_OK) { c->have_imp = false; return rc; }
     c->inx = nx; c->iny = ny; c->inz = nz;
     c->have_imp = true;
+    invalidate_costs(c);
     return VOLYM_OK;
 }
 
@@ -261,6 +298,7 @@ int volym_set_transfer_function(volym_ctx* c, const uint8_t* rgba8, uint32_t n)
     c->tf_n = n;
     c->have_tf = true;
     c->tables_dirty = true;
+    invalidate_costs(c);
     return VOLYM_OK;
 }
 
@@ -318,7 +356,12 @@ static int build_order(volym_ctx* c)
                 if (c->world == 1) continue;          // wholly outside the frame: nothing to store in raster mode
             }
             const int dx = std::abs(2 * x0 + 8 - static_cast<int>(c->W)), dy = std::abs(2 * y0 + 8 - static_cast<int>(c->H));
-            keyed.emplace_back(static_cast<uint32_t>(std::max(dx, dy)), lt * 4u + sub);
+            // rings of 16 pixels; inside a ring a hash decides, so that a workgroup (which takes every G-th item)
+            // does not sit at the same angular position on every ring
+            const uint32_t item = lt * 4u + sub;
+            uint32_t h = item * 0x9E3779B1u;
+            h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+            keyed.emplace_back((static_cast<uint32_t>(std::max(dx, dy)) / 32u) << 20 | (h & 0xfffffu), item);
         }
     }
     std::sort(keyed.begin(), keyed.end());
@@ -326,14 +369,143 @@ static int build_order(volym_ctx* c)
     for (size_t i = 0; i < keyed.size(); ++i) order[i] = keyed[i].second;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->d_order) { HIPCHK(c, hipFree(c->d_order)); c->d_order = nullptr; }
+    if (c->d_cost) { HIPCHK(c, hipFree(c->d_cost)); c->d_cost = nullptr; }
     c->n_items = static_cast<uint32_t>(order.size());
     if (c->n_items) {
         hipError_t e = hipMalloc(&c->d_order, order.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&c->d_cost, static_cast<size_t>(c->n_local) * 4 * sizeof(uint16_t));
         if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(order): ") + hipGetErrorString(e));
         HIPCHK(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemset(c->d_cost, 0, static_cast<size_t>(c->n_local) * 4 * sizeof(uint16_t)));
     }
+    c->h_order = std::move(order);
     c->order_dirty = false;
+    c->order_by_cost = false;
+    c->frames_since_change = 0;
     return VOLYM_OK;
+}
+
+// Scheduling feedback (variant 2).  The frame time is set by the few hundred tiles whose rays take ~10x the
+// average number of dependent samples; they should be the first tickets of every workgroup, and only the
+// previous frame knows which they are.  When a second frame is requested with nothing changed (the
+// reference's benchmark and an idle window render a static view; an orbiting camera never gets here) the
+// work list is re-sorted once by the cost the last launch measured, longest first; ties keep the
+// centre-first order.  Pixels do not depend on the order.
+static int reorder_by_cost(volym_ctx* c)
+{
+    if (!c->n_items || !c->d_cost) return VOLYM_OK;
+    std::vector<uint16_t> cost(static_cast<size_t>(c->n_local) * 4);
+    HIPCHK(c, hipMemcpyAsync(cost.data(), c->d_cost, cost.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> order = c->h_order;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    HIPCHK(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->order_by_cost = true;
+    return VOLYM_OK;
+}
+
+// ---- exact culling inputs (raymarch_pq.h): hulls of the projected unit cube and of the projected AABB of the
+// occupied macro cells, in pixel coordinates, plus the AABB itself.  Double precision on the host; the kernel
+// applies a 1.5 pixel margin, far above the f32 noise of the per-pixel ray set-up it stands in for. ----
+namespace {
+struct P2 { double x, y; };
+
+bool invert4d(const double m[16], double inv[16])
+{
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int col = 0; col < 4; ++col) { a[r][col] = m[col * 4 + r]; a[r][4 + col] = r == col ? 1.0 : 0.0; }
+    for (int i = 0; i < 4; ++i) {
+        int piv = i;
+        for (int r = i + 1; r < 4; ++r) if (std::fabs(a[r][i]) > std::fabs(a[piv][i])) piv = r;
+        if (std::fabs(a[piv][i]) < 1e-300) return false;
+        if (piv != i) for (int k = 0; k < 8; ++k) std::swap(a[i][k], a[piv][k]);
+        const double d = a[i][i];
+        for (int k = 0; k < 8; ++k) a[i][k] /= d;
+        for (int r = 0; r < 4; ++r) if (r != i) { const double f = a[r][i]; if (f != 0.0) for (int k = 0; k < 8; ++k) a[r][k] -= f * a[i][k]; }
+    }
+    for (int r = 0; r < 4; ++r) for (int col = 0; col < 4; ++col) inv[col * 4 + r] = a[r][4 + col];
+    return true;
+}
+
+// convex hull (monotone chain) of <= 8 points -> edges (a, b, c, 1) with |(a,b)| = 1, inside >= 0
+bool hull_edges(const P2* pts, int n, float out[8][4])
+{
+    std::vector<P2> p(pts, pts + n);
+    std::sort(p.begin(), p.end(), [](const P2& u, const P2& v) { return u.x < v.x || (u.x == v.x && u.y < v.y); });
+    auto cross = [](const P2& o, const P2& u, const P2& v) { return (u.x - o.x) * (v.y - o.y) - (u.y - o.y) * (v.x - o.x); };
+    std::vector<P2> h(2 * p.size());
+    int k = 0;
+    for (size_t i = 0; i < p.size(); ++i) { while (k >= 2 && cross(h[k - 2], h[k - 1], p[i]) <= 0) --k; h[k++] = p[i]; }
+    for (size_t i = p.size() - 1, t = k + 1; i > 0; --i) { while (k >= static_cast<int>(t) && cross(h[k - 2], h[k - 1], p[i - 1]) <= 0) --k; h[k++] = p[i - 1]; }
+    const int m = k - 1;                          // closed polygon, last == first
+    for (int e = 0; e < 8; ++e) out[e][0] = out[e][1] = out[e][2] = out[e][3] = 0.0f;
+    if (m < 3 || m > 8) return false;
+    double cx = 0, cy = 0;
+    for (int i = 0; i < m; ++i) { cx += h[i].x; cy += h[i].y; }
+    cx /= m; cy /= m;
+    for (int i = 0; i < m; ++i) {
+        const P2 &u = h[i], &v = h[(i + 1) % m];
+        double a = -(v.y - u.y), b = v.x - u.x;
+        const double len = std::sqrt(a * a + b * b);
+        if (len < 1e-9) return false;
+        a /= len; b /= len;
+        double cc = -(a * u.x + b * u.y);
+        if (a * cx + b * cy + cc < 0) { a = -a; b = -b; cc = -cc; }
+        out[i][0] = static_cast<float>(a); out[i][1] = static_cast<float>(b); out[i][2] = static_cast<float>(cc); out[i][3] = 1.0f;
+    }
+    return true;
+}
+}  // namespace
+
+static void compute_culling(volym_ctx* c)
+{
+    FrameParams& fp = c->fp;
+    fp.cull = 0;
+    std::memset(fp.hull, 0, sizeof fp.hull);
+    c->hull_dirty = false;
+    if (!c->culling) return;
+    // AABB of the occupied cells, grown by what a sample may reach beyond its own position
+    const bool none = c->h_aabb[3] < c->h_aabb[0];
+    if (none) fp.cull |= CULL_NOTHING_DENSE;
+    double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
+    const double margin = 1.0e-4 + ((fp.flags & F_GAUSSIAN) ? 0.0101 : 0.0);   // smoothing taps sit up to 2*0.005 along the ray (wgsl:53-60)
+    if (!none) {
+        for (int i = 0; i < 3; ++i) {
+            lo[i] = static_cast<double>(c->h_aabb[i]) / c->mc_n - margin;
+            hi[i] = static_cast<double>(c->h_aabb[3 + i] + 1) / c->mc_n + margin;
+            fp.aabb_lo[i] = static_cast<float>(lo[i]);
+            fp.aabb_hi[i] = static_cast<float>(hi[i]);
+        }
+        fp.cull |= CULL_AABB;
+    }
+    // world -> clip as the exact inverse of the matrix the rays are generated from
+    double ivp[16], M[16];
+    for (int i = 0; i < 16; ++i) ivp[i] = (&c->cam_copy.inverse_view_proj[0][0])[i];
+    if (!invert4d(ivp, M)) return;
+    auto clip = [&](double x, double y, double z, double out[4]) {
+        for (int r = 0; r < 4; ++r) out[r] = M[0 * 4 + r] * x + M[1 * 4 + r] * y + M[2 * 4 + r] * z + M[3 * 4 + r];
+    };
+    // the eye must be the centre of projection of that matrix (w == 0), otherwise the hulls say nothing about the rays
+    double ce[4];
+    clip(fp.eye[0], fp.eye[1], fp.eye[2], ce);
+    const double scale = std::fabs(M[3]) + std::fabs(M[7]) + std::fabs(M[11]) + std::fabs(M[15]);
+    if (!(std::fabs(ce[3]) <= 1e-4 * scale)) return;
+    auto project_box = [&](const double blo[3], const double bhi[3], float out[8][4]) -> bool {
+        P2 pts[8];
+        for (int k = 0; k < 8; ++k) {
+            double q[4];
+            clip((k & 1) ? bhi[0] : blo[0], (k & 2) ? bhi[1] : blo[1], (k & 4) ? bhi[2] : blo[2], q);
+            if (!(q[3] > 1e-3 * scale)) return false;       // a corner at or behind the eye plane: no hull
+            pts[k].x = (q[0] / q[3] + 1.0) * 0.5 * c->W;     // wgsl:221-229 inverted: pixel = (ndc + 1)/2 * W
+            pts[k].y = (1.0 - q[1] / q[3]) * 0.5 * c->H;
+            if (!std::isfinite(pts[k].x) || !std::isfinite(pts[k].y)) return false;
+        }
+        return hull_edges(pts, 8, out);
+    };
+    const double c0[3] = {0, 0, 0}, c1[3] = {1, 1, 1};
+    if (project_box(c0, c1, fp.hull[0])) fp.cull |= CULL_CUBE_HULL;
+    if (!none && project_box(lo, hi, fp.hull[1])) fp.cull |= CULL_OBJ_HULL;
 }
 
 static int ensure_frame_resources(volym_ctx* c)
@@ -359,12 +531,16 @@ static int ensure_frame_resources(volym_ctx* c)
         c->mc_built_n = c->mc_n;
         c->df_thr_byte = 0xffffffffu;
     }
-    if (c->df_thr_byte != c->fp.thr_byte) {
+    if (c->df_thr_byte != c->thr_byte_cull) {
         // stream order: earlier frames finish reading d_df before this kernel rewrites it
-        hipLaunchKernelGGL(volym_distance_field_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_mc, c->d_df, c->mc_n, c->fp.thr_byte);
+        hipLaunchKernelGGL(volym_distance_field_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_mc, c->d_df, c->d_aabb, c->mc_n, c->thr_byte_cull);
         HIPCHK(c, hipGetLastError());
-        c->df_thr_byte = c->fp.thr_byte;
+        HIPCHK(c, hipMemcpyAsync(c->h_aabb, c->d_aabb, sizeof c->h_aabb, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // only when volume / threshold / grid changed
+        c->df_thr_byte = c->thr_byte_cull;
+        c->hull_dirty = true;
     }
+    if (c->hull_dirty) compute_culling(c);
     return VOLYM_OK;
 }
 
@@ -424,6 +600,23 @@ int volym_update(volym_ctx* c, const volym_camera_uniforms* cam, const volym_par
     for (int b = 255; b >= 0; --b)
         if (c->h_tables.rho[b] >= fp.thr) tb = static_cast<uint32_t>(b); else break;
     fp.thr_byte = tb;
+    // continuous-rho modes (trilinear / smoothed) compare an interpolated value: give its rounding some room
+    if (fp.flags & (F_LINEAR | F_GAUSSIAN)) {
+        const float cons = fp.thr - std::fabs(fp.thr) * 1.0e-5f - 1.0e-7f;
+        uint32_t tc = 256;
+        for (int b = 255; b >= 0; --b)
+            if (c->h_tables.rho[b] >= cons) tc = static_cast<uint32_t>(b); else break;
+        c->thr_byte_cull = tc;
+    } else {
+        c->thr_byte_cull = tb;
+    }
+    if (!c->have_frame || std::memcmp(&c->cam_copy, cam, sizeof *cam) != 0 || std::memcmp(&c->par_copy, par, sizeof *par) != 0) {
+        c->frames_since_change = 0;          // the measured costs describe another view
+        if (c->order_by_cost) c->order_dirty = true;   // back to the geometric order until re-measured
+    }
+    c->cam_copy = *cam;
+    c->par_copy = *par;
+    c->hull_dirty = true;
     c->have_frame = true;
     return VOLYM_OK;
 }
@@ -450,17 +643,27 @@ static int launch_march(volym_ctx* c)
     }
     Counters* cnt = COUNT ? c->d_counters : nullptr;
     uint4* trace = TRACE ? c->d_trace : nullptr;
-    if (c->kernel_variant == 2 && !TRACE) {
+    if (c->kernel_variant == 2) {
         if (c->n_items == 0) return VOLYM_OK;
+        const bool plain = !COUNT && !TRACE;
+        if (plain && c->feedback && !c->order_by_cost && c->frames_since_change == 1) {
+            int rcc = reorder_by_cost(c);
+            if (rcc != VOLYM_OK) return rcc;
+        }
+        uint16_t* cost_out = (plain && c->feedback && !c->order_by_cost) ? c->d_cost : nullptr;
+        if (plain) c->frames_since_change++;
         const uint32_t want = (c->n_items + PQ_WAVES - 1) / PQ_WAVES;
-        const uint32_t pgrid = std::min(want, static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu);
+        const uint32_t pgrid = std::max(1u, std::min(want, static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu));
         const bool table = !(fp.flags & (F_LINEAR | F_GAUSSIAN));
-        if (table)
-            hipLaunchKernelGGL((volym_raymarch_pq_kernel<true, COUNT>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol, c->d_imp,
-                               c->d_tables, c->d_df, c->d_order, c->n_items, c->d_shard, c->d_frame, c->d_f32, cnt, fp);
-        else
-            hipLaunchKernelGGL((volym_raymarch_pq_kernel<false, COUNT>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol, c->d_imp,
-                               c->d_tables, c->d_df, c->d_order, c->n_items, c->d_shard, c->d_frame, c->d_f32, cnt, fp);
+#define VOLYM_PQ_LAUNCH(T, KS)                                                                                                   \
+    hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT, TRACE, KS>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,  \
+                       c->d_imp, c->d_tables, c->d_df, c->d_order, c->n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
+        if (table && c->kspec == 8) VOLYM_PQ_LAUNCH(true, 8);
+        else if (table && c->kspec == 4) VOLYM_PQ_LAUNCH(true, 4);
+        else if (table && c->kspec == 2) VOLYM_PQ_LAUNCH(true, 2);
+        else if (table) VOLYM_PQ_LAUNCH(true, 1);
+        else VOLYM_PQ_LAUNCH(false, 1);
+#undef VOLYM_PQ_LAUNCH
         HIPCHK(c, hipGetLastError());
         return VOLYM_OK;
     }

@@ -48,6 +48,18 @@ struct FrameParams {
     uint32_t xcd_bands;              // block -> tile remap granularity (0 = identity)
     float gauss_w[5];
     float cone_cos[8], cone_sin[8];
+    // ---- exact culling (VARIANT 2; see raymarch_pq.h) ----
+    uint32_t cull;           // CULL_* bits
+    float hull[2][8][4];     // [0] projected unit cube, [1] projected AABB of the occupied macro cells:
+                             // up to 8 edges (a, b, c, valid) in pixel units, |(a,b)| = 1, inside: a*x + b*y + c >= 0
+    float aabb_lo[3], aabb_hi[3];   // AABB of the occupied macro cells, already grown by its safety margin
+};
+
+enum : uint32_t {
+    CULL_CUBE_HULL = 1u << 0,   // hull[0] is usable (every cube corner in front of the eye)
+    CULL_OBJ_HULL = 1u << 1,    // hull[1] is usable
+    CULL_AABB = 1u << 2,        // aabb_lo/hi are valid: no sample outside it can reach the threshold
+    CULL_NOTHING_DENSE = 1u << 3,   // no macro cell can reach the threshold at all
 };
 
 // Per-(transfer function, parameters) tables, built on the host with the same wgsl_math.h

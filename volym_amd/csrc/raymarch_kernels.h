@@ -295,39 +295,73 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
 }
 
 // Chebyshev distance (in cells, capped at 15) from every macro cell to the nearest cell that may
-// hold a voxel >= thr_byte; 0 for such cells.  Cells outside the grid count as empty.  One
-// workgroup, whole grid in LDS; packed two cells per byte (low nibble = even cell).
+// hold a voxel >= thr_byte; 0 for such cells.  Cells outside the grid count as empty.  Output packed
+// two cells per byte (low nibble = even cell).  Also emits the AABB of the occupied cells.
+//
+// One workgroup, bit-parallel: thread r owns the row (y, z) = (r % n, r / n) as one 32-bit word (bit x).
+// mask_0 = occupied, mask_k = mask_{k-1} dilated by one cell along x, y and z (a 3x3x3 box); the masks
+// are nested, so D(c) = #{k in 0..14 : c not in mask_k}, accumulated in four bit planes.
 __global__ __launch_bounds__(1024) void volym_distance_field_kernel(const uint8_t* __restrict__ mc_max, uint8_t* __restrict__ df4,
-                                                                    uint32_t mc_n, uint32_t thr_byte)
+                                                                    int* __restrict__ aabb, uint32_t mc_n, uint32_t thr_byte)
 {
-    __shared__ uint8_t d[32 * 32 * 32];
-    const uint32_t cells = mc_n * mc_n * mc_n;
-    for (uint32_t c = threadIdx.x; c < cells; c += 1024u) d[c] = mc_max[c] >= thr_byte ? 0 : 15;
+    __shared__ uint32_t rows[32 * 32];
+    __shared__ uint32_t tmp[32 * 32];
+    __shared__ int s_box[6];
+    const uint32_t r = threadIdx.x, n = mc_n;
+    const bool live = r < n * n;
+    const uint32_t y = live ? r % n : 0u, z = live ? r / n : 0u;
+    if (r < 6u) s_box[r] = (r < 3u) ? static_cast<int>(n) : -1;
+    uint32_t m = 0;
+    if (live)
+        for (uint32_t x = 0; x < n; ++x)
+            if (mc_max[x + n * (y + n * z)] >= thr_byte) m |= 1u << x;
     __syncthreads();
-    // D(c) = min(D(c), 1 + min over the 26 neighbours): values only decrease and never drop below
-    // the true distance, so in-place relaxation is safe; 14 sweeps reach every distance <= 15.
-    for (int sweep = 0; sweep < 14; ++sweep) {
-        for (uint32_t c = threadIdx.x; c < cells; c += 1024u) {
-            const int x = static_cast<int>(c % mc_n), y = static_cast<int>((c / mc_n) % mc_n), z = static_cast<int>(c / (mc_n * mc_n));
-            uint32_t best = d[c];
-            if (best > 1u) {
-                for (int dz = -1; dz <= 1; ++dz)
-                    for (int dy = -1; dy <= 1; ++dy)
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            const int xx = x + dx, yy = y + dy, zz = z + dz;
-                            if (xx < 0 || yy < 0 || zz < 0 || xx >= static_cast<int>(mc_n) || yy >= static_cast<int>(mc_n) || zz >= static_cast<int>(mc_n)) continue;
-                            const uint32_t v = d[static_cast<uint32_t>(xx) + mc_n * (static_cast<uint32_t>(yy) + mc_n * static_cast<uint32_t>(zz))] + 1u;
-                            best = v < best ? v : best;
-                        }
-                d[c] = static_cast<uint8_t>(best);
-            }
+    if (live && m) {
+        atomicMin(&s_box[0], __builtin_ctz(m));
+        atomicMax(&s_box[3], 31 - __builtin_clz(m));
+        atomicMin(&s_box[1], static_cast<int>(y)); atomicMax(&s_box[4], static_cast<int>(y));
+        atomicMin(&s_box[2], static_cast<int>(z)); atomicMax(&s_box[5], static_cast<int>(z));
+    }
+    const uint32_t row_mask = n >= 32u ? 0xffffffffu : ((1u << n) - 1u);
+    uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;             // bit planes of the per-cell count
+    for (int k = 0; k < 15; ++k) {
+        // count += !mask_k  (bit-sliced ripple add of a one-bit addend)
+        uint32_t carry = ~m & row_mask;
+        uint32_t t0 = p0 & carry; p0 ^= carry; carry = t0;
+        t0 = p1 & carry; p1 ^= carry; carry = t0;
+        t0 = p2 & carry; p2 ^= carry; carry = t0;
+        p3 ^= carry;
+        if (k == 14) break;
+        // dilate: x in-register, then y and z through LDS
+        m = (m | (m << 1) | (m >> 1)) & row_mask;
+        if (live) rows[r] = m;
+        __syncthreads();
+        if (live) {
+            uint32_t v = m;
+            if (y > 0u) v |= rows[r - 1u];
+            if (y + 1u < n) v |= rows[r + 1u];
+            tmp[r] = v;
+        }
+        __syncthreads();
+        if (live) {
+            uint32_t v = tmp[r];
+            if (z > 0u) v |= tmp[r - n];
+            if (z + 1u < n) v |= tmp[r + n];
+            m = v;
         }
         __syncthreads();
     }
-    for (uint32_t k = threadIdx.x; k < (cells + 1u) / 2u; k += 1024u) {
-        const uint32_t lo = d[2u * k], hi = 2u * k + 1u < cells ? d[2u * k + 1u] : 0u;
-        df4[k] = static_cast<uint8_t>(lo | (hi << 4));
+    if (live) {
+        uint8_t* out = df4 + (static_cast<size_t>(n) * (y + n * z)) / 2u;
+        for (uint32_t x = 0; x < n; x += 2u) {
+            const uint32_t lo = ((p0 >> x) & 1u) | (((p1 >> x) & 1u) << 1) | (((p2 >> x) & 1u) << 2) | (((p3 >> x) & 1u) << 3);
+            const uint32_t x1 = x + 1u;
+            const uint32_t hi = ((p0 >> x1) & 1u) | (((p1 >> x1) & 1u) << 1) | (((p2 >> x1) & 1u) << 2) | (((p3 >> x1) & 1u) << 3);
+            out[x / 2u] = static_cast<uint8_t>(lo | (hi << 4));
+        }
     }
+    __syncthreads();
+    if (r < 6u) aabb[r] = s_box[r];
 }
 
 // per-cell maxima of the density volume: cell (cx,cy,cz) of the mc_n^3 grid covers the voxels a

@@ -20,19 +20,31 @@
 //     REAL classes and stop at the first misprediction.  Accepted samples are bit-identical to the
 //     sequential march (same f32 operations in the same order).
 //
-// Work distribution: persistent workgroups of 8 waves; the 8x8-pixel wave tiles of this rank are
-// sorted centre-first on the host (the orbit camera always targets the volume centre, src/camera.rs:23,
-// so the expensive tiles are the central ones) and wave g takes items g, g+G, g+2G, ...: the long
-// rays start first and the cheap border tiles fill in behind them.  No atomics, no inter-workgroup
-// communication.
+// Work distribution: persistent workgroups of PQ_WAVES waves, one or two per CU.  The host sorts this
+// rank's 8x8-pixel wave tiles centre-first (the orbit camera always targets the volume centre,
+// src/camera.rs:23, so the expensive tiles tend to be the central ones); workgroup b owns items
+// b, b+G, b+2G, ... (every workgroup gets the same mix of radii) and its waves take them in that order
+// through a ticket counter in LDS: dynamic balance inside the workgroup, no global atomics, nothing to
+// reset between launches, no inter-workgroup communication.
+//
+// Exact culling (results unchanged, DESIGN.md "Culling"):
+//   * no sample outside the AABB of the occupied macro cells can reach the threshold, so a ray is
+//     replayed (t += cur in f32, no fetches) up to the AABB entry and abandoned at its exit; a ray that
+//     misses the AABB is final at (0,0,0,0);
+//   * a wave tile whose 8x8 pixel rectangle lies outside the projected cube stores (0,0,0,1) and one
+//     inside the cube but outside the projected AABB stores (0,0,0,0) without any per-ray work.  Both
+//     tests use hulls projected on the host and a 1.5 pixel safety margin; tiles that straddle an
+//     edge take the exact per-ray path.
+// The instrumented (COUNT) launch disables culling: it counts what the reference would fetch.
 #pragma once
 
 #include "raymarch_device.h"
 
 namespace volym {
 
-constexpr int PQ_WAVES = 8;              // waves per workgroup
+constexpr int PQ_WAVES = 16;             // waves per workgroup
 constexpr int PQ_THREADS = PQ_WAVES * 64;
+constexpr uint32_t PQ_MIN_LEAP_D = 2;    // smallest distance-field value worth a leap
 constexpr int PQ_QCAP = 128;             // ring entries per wave (>= 64 queued + 64 new)
 constexpr float PQ_FIX_SCALE = 268435456.0f;        // 2^28
 constexpr float PQ_FIX_INV = 1.0f / 268435456.0f;
@@ -42,13 +54,42 @@ __device__ __forceinline__ uint32_t lane_rank_in_mask(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
-template <bool TABLE, bool COUNT>
+enum : uint32_t { TILE_MARCH = 0, TILE_HIT_TEST = 1, TILE_FILL_EMPTY = 2, TILE_FILL_MISS = 3 };
+
+// Classify the pixel rectangle [x0, x0+7] x [y0, y0+7] against the two projected hulls (wave-uniform
+// result; lane l evaluates hull l>>5, edge (l>>2)&7, corner l&3).
+__device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, uint32_t lane, float x0, float y0)
+{
+    const uint32_t h = lane >> 5, e = (lane >> 2) & 7u, k = lane & 3u;
+    const float cx = (k & 1u) ? x0 + 7.0f : x0, cy = (k & 2u) ? y0 + 7.0f : y0;
+    const float a = fp.hull[h][e][0], b = fp.hull[h][e][1], c = fp.hull[h][e][2];
+    const bool valid = fp.hull[h][e][3] > 0.5f;
+    const float v = __builtin_fmaf(a, cx, __builtin_fmaf(b, cy, c));
+    const float margin = 1.5f;
+    const unsigned long long mo = __ballot(valid && v < -margin);     // corner strictly outside edge
+    const unsigned long long mi = __ballot(!valid || v > margin);     // corner strictly inside edge
+    auto outside = [&](uint32_t bits) { return ((bits & (bits >> 1) & (bits >> 2) & (bits >> 3)) & 0x11111111u) != 0u; };
+    const bool cube_ok = (fp.cull & CULL_CUBE_HULL) != 0u, obj_ok = (fp.cull & CULL_OBJ_HULL) != 0u;
+    const bool out_cube = cube_ok && outside(static_cast<uint32_t>(mo));
+    const bool in_cube = cube_ok && static_cast<uint32_t>(mi) == 0xffffffffu;
+    const bool out_obj = (fp.cull & CULL_NOTHING_DENSE) != 0u || (obj_ok && outside(static_cast<uint32_t>(mo >> 32)));
+    if (out_cube) return TILE_FILL_MISS;
+    if (out_obj) return in_cube ? TILE_FILL_EMPTY : TILE_HIT_TEST;
+    return TILE_MARCH;
+}
+template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1>
 __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
-    const uint8_t* __restrict__ df4, const uint32_t* __restrict__ order, uint32_t n_items, uint32_t* __restrict__ out_shard,
-    uint32_t* __restrict__ out_raster, float4* __restrict__ out_f32, Counters* __restrict__ counters, const FrameParams fp)
+    const uint8_t* __restrict__ df4, const uint32_t* __restrict__ order, uint32_t n_items, uint16_t* __restrict__ cost,
+    uint32_t* __restrict__ out_shard, uint32_t* __restrict__ out_raster, float4* __restrict__ out_f32,
+    Counters* __restrict__ counters, uint4* __restrict__ trace, const FrameParams fp)
 {
-    constexpr int K = TABLE ? 4 : 1;     // speculation depth
+    constexpr int K = TABLE ? KSPEC : 1;     // speculation depth
+    unsigned long long trace_t0 = 0;
+    uint32_t trace_iters = 0, trace_flushes = 0, trace_tiles = 0, trace_marched = 0;
+    unsigned long long tm_leap = 0, tm_samp = 0, tm_flush = 0, tm_setup = 0, tm_mark = 0;
+#define PQ_TICK() (TRACE ? __builtin_amdgcn_s_memtime() : 0ull)
+    if (TRACE) trace_t0 = __builtin_amdgcn_s_memrealtime();
 
     __shared__ float4 s_tf_tab[256];
     __shared__ float4 s_lut[TABLE ? 1 : 256];
@@ -59,6 +100,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     __shared__ uint32_t s_qm[PQ_WAVES][PQ_QCAP];
     __shared__ float s_qr[TABLE ? 1 : PQ_WAVES][TABLE ? 1 : PQ_QCAP];
     __shared__ uint32_t s_acc[PQ_WAVES][3][64];
+    __shared__ uint32_t s_next_ticket;
 
     const uint32_t flags = fp.flags;
     const bool linear = (flags & F_LINEAR) != 0u;
@@ -69,6 +111,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
 
     {
         const uint32_t i = threadIdx.x;
+        if (i == 0u) s_next_ticket = 0u;
         if (i < 256u) {
             s_tf_tab[i] = tables->tf_tab[i];
             s_rho[i] = tables->rho[i];
@@ -86,7 +129,6 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t total_waves = gridDim.x * PQ_WAVES;
 
     Grid g;
     g.vol = vol; g.imp = imp;
@@ -109,14 +151,45 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     const float base = fp.base_step, min_step = fp.min_step, thr = fp.thr;
     const float mcf = static_cast<float>(fp.mc_n), inv_mc = 1.0f / mcf;
 
-    for (uint32_t item_idx = blockIdx.x * PQ_WAVES + wave; item_idx < n_items; item_idx += total_waves) {
-        const uint32_t item = __builtin_amdgcn_readfirstlane(order[item_idx]);
+    // ---- work distribution: this workgroup owns items b, b+G, ...; its waves draw them in order ----
+    const uint32_t n_mine = n_items > blockIdx.x ? (n_items - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+    auto grab = [&]() -> uint32_t {
+        uint32_t ticket = 0;
+        if (lane == 0) ticket = atomicAdd(&s_next_ticket, 1u);
+        return __builtin_amdgcn_readfirstlane(ticket);
+    };
+    const bool culling = !COUNT && fp.cull != 0u;
+    for (uint32_t ticket = grab(); ticket < n_mine; ticket = grab()) {
+      {
+        const uint32_t item = __builtin_amdgcn_readfirstlane(order[blockIdx.x + static_cast<size_t>(gridDim.x) * ticket]);
         const uint32_t local_tile = item >> 2, sub = item & 3u;
         const uint32_t tile = local_tile * fp.world + fp.rank;
         const uint32_t tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
         const uint32_t gx = tx * 16u + ((sub & 1u) << 3) + (lane & 7u);
         const uint32_t gy = ty * 16u + ((sub >> 1) << 3) + (lane >> 3);
         const bool in_frame = gx < fp.W && gy < fp.H;   // wgsl:217-219
+
+        if (TRACE) { trace_tiles++; tm_mark = PQ_TICK(); }
+        uint32_t tile_iters = 0, tile_flushes = 0;      // measured cost of this tile, fed back to the scheduler
+        uint32_t tclass = TILE_MARCH;
+        if (culling) {
+            tclass = classify_tile(fp, lane, static_cast<float>(tx * 16u + ((sub & 1u) << 3)), static_cast<float>(ty * 16u + ((sub >> 1) << 3)));
+            if (tclass >= TILE_FILL_EMPTY) {            // no ray of this tile can differ from the constant
+                const uint32_t packed = tclass == TILE_FILL_MISS ? 0xff000000u : 0u;     // (0,0,0,1) wgsl:239 / (0,0,0,0) wgsl:328
+                if (flags & F_RASTER) {
+                    if (in_frame) {
+                        const size_t o = static_cast<size_t>(gy) * fp.W + gx;
+                        out_raster[o] = packed;
+                        if (flags & F_WRITE_F32) out_f32[o] = make_float4(0.0f, 0.0f, 0.0f, tclass == TILE_FILL_MISS ? 1.0f : 0.0f);
+                    }
+                } else {
+                    out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + lane] = in_frame ? packed : 0u;
+                }
+                if (cost && lane == 0) cost[item] = 0;
+                continue;
+            }
+        }
+        if (TRACE) trace_marched++;
 
         acc_r[lane] = 0u; acc_g[lane] = 0u; acc_b[lane] = 0u;
         uint32_t q_head = 0, q_count = 0;               // wave-uniform ring state
@@ -128,14 +201,45 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         if (COUNT && active) n_hit++;
         float t = active ? ray.t_entry : 0.0f, cur = base, acc_a = active ? 0.0f : 1.0f;   // miss: (0,0,0,1) wgsl:239
         bool last_dense = false;
+        if (culling && tclass == TILE_HIT_TEST) active = false;     // hit rays of this tile see nothing dense: (0,0,0,0)
+        float t_end = ray.t_exit;                        // samples at t >= t_end cannot be dense
+        if (culling && (fp.cull & CULL_AABB) && active) {
+            // slab test against the AABB of the occupied macro cells (conservative arithmetic)
+            const float rx = 1.0f / ray.d.x, ry = 1.0f / ray.d.y, rz = 1.0f / ray.d.z;
+            const float ax0 = (fp.aabb_lo[0] - ray.o.x) * rx, ax1 = (fp.aabb_hi[0] - ray.o.x) * rx;
+            const float ay0 = (fp.aabb_lo[1] - ray.o.y) * ry, ay1 = (fp.aabb_hi[1] - ray.o.y) * ry;
+            const float az0 = (fp.aabb_lo[2] - ray.o.z) * rz, az1 = (fp.aabb_hi[2] - ray.o.z) * rz;
+            float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)), __builtin_fminf(az0, az1));
+            float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)), __builtin_fmaxf(az0, az1));
+            tn = tn - 2.0e-5f * __builtin_fabsf(tn) - 1.0e-6f;
+            tf = tf + 2.0e-5f * __builtin_fabsf(tf) + 1.0e-6f;
+            // a zero direction component makes its slab pair NaN/inf: fmin/fmax drop NaN, so test the origin there
+            const bool outside_static = (ray.d.x == 0.0f && (ray.o.x < fp.aabb_lo[0] || ray.o.x > fp.aabb_hi[0])) ||
+                                        (ray.d.y == 0.0f && (ray.o.y < fp.aabb_lo[1] || ray.o.y > fp.aabb_hi[1])) ||
+                                        (ray.d.z == 0.0f && (ray.o.z < fp.aabb_lo[2] || ray.o.z > fp.aabb_hi[2]));
+            if (outside_static || !(tn <= tf)) {
+                active = false;                          // never inside the AABB: nothing dense on this ray
+            } else {
+                t_end = __builtin_fminf(t_end, tf);
+                // replay of the empty steps in front of the AABB (wgsl:263-274), cur == base throughout
+                const float t_first = __builtin_fminf(tn, t_end);
+                while (t < t_first) {
+                    cur = __builtin_fminf(base, cur * 1.5f);
+                    t += cur;
+                }
+            }
+        }
         const float idx_ = 1.0f / ray.d.x, idy_ = 1.0f / ray.d.y, idz_ = 1.0f / ray.d.z;
         const float nox = -ray.o.x * idx_, noy = -ray.o.y * idy_, noz = -ray.o.z * idz_;
 
         // ---- shade up to 64 queued samples, one per lane (COLOUR arithmetic) ----
         auto flush = [&](uint32_t n) {
+            unsigned long long fl0 = 0;
+            tile_flushes++;
+            if (TRACE) { trace_flushes++; fl0 = PQ_TICK(); }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lane < n) {
+            if (lane < n && !(fp.xcd_bands & 0x100u)) {   // bit 8 of the dev knob: skip shading (timing experiment only)
                 const uint32_t e = (q_head + lane) & (PQ_QCAP - 1);
                 const V3 pos = v3(qx[e], qy[e], qz[e]);
                 const float w = qw[e];
@@ -184,6 +288,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             q_count -= n;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (TRACE) tm_flush += PQ_TICK() - fl0;
         };
 
         // ---- push the samples flagged by `emit` (any subset of lanes), shade when 64 are waiting ----
@@ -199,11 +304,18 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             if (q_count >= 64u) flush(64u);
         };
 
+        if (TRACE) { const unsigned long long now = PQ_TICK(); tm_setup += now - tm_mark; tm_mark = now; }
         while (__ballot(active) != 0ull) {
-            // ---- 1. leap through provably empty macro cells (see raymarch_kernels.h VARIANT 1) ----
+            tile_iters++;
+            if (TRACE) { trace_iters++; tm_mark = PQ_TICK(); }
+            // ---- 1. at most ONE leap per lane and iteration through provably empty macro cells (see
+            // raymarch_kernels.h VARIANT 1).  Cells with distance value < PQ_MIN_LEAP_D are simply sampled:
+            // a one-cell leap replays ~3 steps, which the K-wide speculation below covers in the same
+            // iteration without the ~100 instructions and the LDS round trip of a leap. ----
             if (TABLE && active) {
-                for (;;) {
-                    if (!(t < ray.t_exit && acc_a < 0.95f)) { active = false; break; }   // wgsl:250
+                if (!(t < t_end && acc_a < 0.95f)) {              // wgsl:250 (t_end: nothing dense beyond)
+                    active = false;
+                } else if (!last_dense) {
                     const V3 pos = ray.o + ray.d * t;
                     const float cxf = __builtin_floorf(pos.x * mcf), cyf = __builtin_floorf(pos.y * mcf), czf = __builtin_floorf(pos.z * mcf);
                     const int cx = static_cast<int>(cxf), cy = static_cast<int>(cyf), cz = static_cast<int>(czf);
@@ -212,29 +324,30 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         const uint32_t ci = static_cast<uint32_t>(cx) + fp.mc_n * (static_cast<uint32_t>(cy) + fp.mc_n * static_cast<uint32_t>(cz));
                         D = (static_cast<uint32_t>(s_df[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
                     }
-                    if (D == 0u) break;
-                    const float eps = 4.0e-5f;
-                    const float a = static_cast<float>(D - 1u) * inv_mc - eps;
-                    const float lx = __builtin_fmaf(cxf, inv_mc, -a), hx = __builtin_fmaf(cxf, inv_mc, a + inv_mc);
-                    const float ly = __builtin_fmaf(cyf, inv_mc, -a), hy = __builtin_fmaf(cyf, inv_mc, a + inv_mc);
-                    const float lz = __builtin_fmaf(czf, inv_mc, -a), hz = __builtin_fmaf(czf, inv_mc, a + inv_mc);
-                    const float ex = __builtin_fmaxf(__builtin_fmaf(lx, idx_, nox), __builtin_fmaf(hx, idx_, nox));
-                    const float ey = __builtin_fmaxf(__builtin_fmaf(ly, idy_, noy), __builtin_fmaf(hy, idy_, noy));
-                    const float ez = __builtin_fmaxf(__builtin_fmaf(lz, idz_, noz), __builtin_fmaf(hz, idz_, noz));
-                    float te = __builtin_fminf(__builtin_fminf(ex, ey), ez);
-                    te = te - 2.0e-5f * __builtin_fabsf(te);
-                    const bool inside = pos.x > lx && pos.x < hx && pos.y > ly && pos.y < hy && pos.z > lz && pos.z < hz;
-                    const float t_stop = __builtin_fminf(te, ray.t_exit);
-                    if (!(inside && t < t_stop)) break;
-                    do {                                          // replay of empty steps, wgsl:263-274
-                        if (COUNT) { n_steps++; n_vol++; n_imp++; }
-                        cur = __builtin_fminf(base, cur * 1.5f);
-                        t += cur;
-                    } while (t < t_stop);
-                    last_dense = false;
+                    if (D >= PQ_MIN_LEAP_D) {
+                        const float eps = 4.0e-5f;
+                        const float a = static_cast<float>(D - 1u) * inv_mc - eps;
+                        const float lx = __builtin_fmaf(cxf, inv_mc, -a), hx = __builtin_fmaf(cxf, inv_mc, a + inv_mc);
+                        const float ly = __builtin_fmaf(cyf, inv_mc, -a), hy = __builtin_fmaf(cyf, inv_mc, a + inv_mc);
+                        const float lz = __builtin_fmaf(czf, inv_mc, -a), hz = __builtin_fmaf(czf, inv_mc, a + inv_mc);
+                        const float ex = __builtin_fmaxf(__builtin_fmaf(lx, idx_, nox), __builtin_fmaf(hx, idx_, nox));
+                        const float ey = __builtin_fmaxf(__builtin_fmaf(ly, idy_, noy), __builtin_fmaf(hy, idy_, noy));
+                        const float ez = __builtin_fmaxf(__builtin_fmaf(lz, idz_, noz), __builtin_fmaf(hz, idz_, noz));
+                        float te = __builtin_fminf(__builtin_fminf(ex, ey), ez);
+                        te = te - 2.0e-5f * __builtin_fabsf(te);
+                        // D >= 2: the cell of pos lies at least one whole cell inside the box, no `inside` test needed
+                        const float t_stop = __builtin_fminf(te, t_end);
+                        while (t < t_stop) {                          // replay of empty steps, wgsl:263-274
+                            if (COUNT) { n_steps++; n_vol++; n_imp++; }
+                            cur = __builtin_fminf(base, cur * 1.5f);
+                            t += cur;
+                        }
+                        if (!(t < t_end)) active = false;             // wgsl:250
+                    }
                 }
             }
 
+            if (TRACE) { const unsigned long long now = PQ_TICK(); tm_leap += now - tm_mark; tm_mark = now; }
             // ---- 2. K speculative samples: positions under the prediction "class stays last_dense" ----
             float ts[K];
             uint32_t offs[K], bs[K], ibs[K];
@@ -266,7 +379,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 bool emit = false;
                 V3 pos = v3(0.0f, 0.0f, 0.0f);
                 float w = 0.0f;
-                if (valid && !(t < ray.t_exit && acc_a < 0.95f)) { active = false; valid = false; }   // wgsl:250
+                if (valid && !(t < t_end && acc_a < 0.95f)) { active = false; valid = false; }   // wgsl:250
                 if (valid) {
                     if (COUNT) { n_steps++; n_imp++; }            // wgsl:260 fetches importance every step
                     pos = ray.o + ray.d * t;                      // t == ts[k] bit for bit while valid
@@ -320,6 +433,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 }
                 append(emit, pos, w, lane | (bs[k] << 8) | (ibs[k] << 16), rhos[k]);
             }
+            if (TRACE) tm_samp += PQ_TICK() - tm_mark;
         }
         if (q_count) flush(q_count);
 
@@ -338,10 +452,18 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         } else if (!(flags & F_RASTER)) {
             out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + lane] = 0u;
         }
+        if (cost && lane == 0) cost[item] = static_cast<uint16_t>(min(65535u, 1u + tile_iters * 8u + tile_flushes * 3u));
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
+      }
     }
 
+    if (TRACE && lane == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        const size_t rec = (static_cast<size_t>(blockIdx.x) * PQ_WAVES + wave) * 2u;
+        trace[rec] = make_uint4(static_cast<uint32_t>(trace_t0), static_cast<uint32_t>(t1 - trace_t0), trace_iters | (trace_tiles << 16), trace_flushes | (trace_marched << 16));
+        trace[rec + 1] = make_uint4(static_cast<uint32_t>(tm_leap >> 4), static_cast<uint32_t>((tm_samp - tm_flush) >> 4), static_cast<uint32_t>(tm_flush >> 4), static_cast<uint32_t>(tm_setup >> 4));
+    }
     if (COUNT) {
         unsigned long long v[5] = {n_vol, n_imp, n_steps, n_dense, n_hit};
 #pragma unroll
