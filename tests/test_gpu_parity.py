@@ -292,3 +292,79 @@ def test_error_behaviour(volym_lib):
     with pytest.raises(_lib.VolymError) as e:
         demo.GpuContext(0, 10, 0)
     assert e.value.code == _lib.E_INVALID
+
+
+def test_culling_and_feedback_leave_pixels_unchanged(oracle, volym_lib):
+    """The default kernel's exact culling (projected hulls, AABB clip) and its cost-feedback reordering are
+    scheduling/skipping devices only: frames with them on, off, and before/after the reorder are identical
+    bit for bit, for a pose where the cube is partly off-screen and one where it is small."""
+    from volym_amd import _lib, scene
+    raw, labels = common.bonsai(64)
+    dims = (64, 64, 64)
+    W, H = 200, 120
+    volume = scene.prepare_volume(raw, dims, True)
+    importances = scene.prepare_volume(scene.map_segments_to_importance(labels, common.BONSAI_SEGMENTS), dims, True)
+    with _ctx(W, H) as ctx:
+        ctx.set_volume(volume, dims, 0)
+        ctx.set_importances(importances, dims)
+        ctx.set_transfer_function(scene.default_lut())
+        ctx.set_option(_lib.OPT_KERNEL, 2)
+        for pose in ((0.0, 0.0, 0.0), (40.0, 25.0, 3.0), (10.0, -70.0, 0.2)):
+            for kw in (dict(), dict(use_gaussian_smoothing=1), dict(use_importance_rendering=1, importance_check_ahead_steps=5)):
+                cam = oracle.benchmark_camera_uniforms(W / H, *pose)
+                par = oracle.make_parameters(**kw)
+                cu = _lib.CameraUniforms.from_buffer_copy(bytes(cam))
+                pu = _lib.ParameterUniforms.from_buffer_copy(bytes(par))
+                frames = []
+                for cull, feedback in ((0, 0), (1, 0), (1, 1)):
+                    ctx.set_option(103, cull)
+                    ctx.set_option(104, feedback)
+                    ctx.update(cu, pu)
+                    for _ in range(3):                       # frame 2 triggers the cost reorder when feedback is on
+                        ctx.compute_pass()
+                        ctx.sync()
+                        frames.append((ctx.read_rgba8(), ctx.read_rgba32f()))
+                for u, f in frames[1:]:
+                    assert np.array_equal(u, frames[0][0]) and np.array_equal(f.view(np.uint32), frames[0][1].view(np.uint32)), (pose, kw)
+        ctx.set_option(103, 1)
+        ctx.set_option(104, 1)
+
+
+def test_shard_layout_matches_host_mirror(oracle, volym_lib):
+    """The kernel's shard bytes equal volym_amd/sharding.py's pack_shard of the full frame, and the HIP
+    assemble kernel equals the mirror's assemble (the CPU gloo test relies on that mirror)."""
+    from volym_amd import _lib, demo, scene, sharding
+    raw, labels = common.bonsai(64)
+    dims = (64, 64, 64)
+    W, H = 150, 90                                          # ragged: partial tiles on both edges
+    cam = oracle.benchmark_camera_uniforms(W / H)
+    cu = _lib.CameraUniforms.from_buffer_copy(bytes(cam))
+    pu = _lib.ParameterUniforms.from_buffer_copy(bytes(oracle.make_parameters()))
+    volume = scene.prepare_volume(raw, dims, True)
+    zeros = np.zeros(64 ** 3, np.uint8)
+
+    def render(rank, world, variant):
+        with demo.GpuContext(W, H, 0) as c:
+            c.set_option(_lib.OPT_KERNEL, variant)
+            c.set_shard(rank, world)
+            c.set_volume(volume, dims, 0)
+            c.set_importances(zeros, dims)
+            c.set_transfer_function(scene.default_lut())
+            c.update(cu, pu)
+            c.compute_pass()
+            c.sync()
+            return c.read_rgba8() if world == 1 else c.read_shard()
+
+    full = render(0, 1, 2)
+    for variant in (1, 2):
+        for world in (2, 5):
+            shards = [render(r, world, variant) for r in range(world)]
+            for r in range(world):
+                assert shards[r].size == sharding.shard_bytes(W, H, world)
+                assert np.array_equal(shards[r], sharding.pack_shard(full, r, world)), (variant, world, r)
+            with demo.GpuContext(W, H, 0) as root:
+                root.set_shard(0, world)
+                root.assemble_host(np.concatenate(shards))
+                root.sync()
+                assert np.array_equal(root.read_rgba8(), full)
+            assert np.array_equal(sharding.assemble(np.concatenate(shards), W, H, world), full)
