@@ -88,7 +88,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--volume", type=int, default=256)
     ap.add_argument("--step", type=float, default=0.01)
-    ap.add_argument("--kernel", type=int, default=1, help="0 direct (config 2), 1 macro-cell (config 3)")
+    ap.add_argument("--kernel", type=int, default=2,
+                    help="0 direct (BASELINE configs[1]), 1 macro-cell, 2 persistent + LDS staging + shading queue (configs[2], default)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the driver's runs) or gloo (rehearsal on one device)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
     ap.add_argument("--linear", action="store_true", help="trilinear volume filter (north_star mode)")
     ap.add_argument("--importance", action="store_true")
     ap.add_argument("--cone", action="store_true")
@@ -109,11 +112,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     dims, volume, importances, lut, state = build_scene(args)
     W, H = args.width, args.height
@@ -199,6 +207,18 @@ def main():
     frame_bytes = n_vol * b_vol + n_imp + 4 * W * H                           # whole frame (B_alg)
     achieved = local_bytes / (kernel_ms * 1e-3) / 1e9
 
+    # HBM-side traffic of one launch: PMC counters cannot be read from inside this process; use the committed
+    # rocprofv3 measurement of this exact workload when there is one (profiles/rNN_traffic.json)
+    traffic, traffic_src = None, None
+    if world == 1 and args.kernel == 2 and not (args.linear or args.importance or args.cone) and (W, H, args.volume, args.step) == (1920, 1080, 256, 0.01):
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+            try:
+                traffic = int(json.load(open(f))["traffic_bytes_per_launch"])
+                traffic_src = os.path.basename(f)
+                break
+            except Exception:
+                pass
     if rank == 0:
         rays = W * H
         out = {
@@ -218,7 +238,7 @@ def main():
                 "workload": "bonsai %d^3 uint8 @ %dx%d, %s filter, step %g, thr 0.15, opacity on%s, kernel=%s (BASELINE configs[%d])"
                             % (args.volume, W, H, "linear" if args.linear else "nearest (reference parity)", args.step,
                                ", importance look-ahead %s" % ("cone" if args.cone else "straight") if args.importance else "",
-                               "macro-cell" if args.kernel == 1 else "direct", 2 if args.kernel == 1 else 1),
+                               {0: "direct", 1: "macro-cell", 2: "persistent+LDS-staged+queue"}[args.kernel], 1 if args.kernel == 0 else 2),
                 "viewport": [W, H], "volume": list(dims), "tile_sharding": "interleaved 16x16 tiles, k %% %d" % world,
             },
             "achieved_gbs": frame_bytes * args.steps / dt / 1e9,
@@ -226,8 +246,8 @@ def main():
             "b_alg_bytes_per_ray": frame_bytes / rays,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "volym_raymarch_kernel<%d,false>" % args.kernel,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "volym_raymarch_pq_kernel<true,false,false,4>" if args.kernel == 2 else "volym_raymarch_kernel<%d,false,false>" % args.kernel,
                 "kernel_avg_ms": kernel_ms, "launch_algorithmic_bytes": local_bytes,
                 "note": "algorithmic bytes = reference fetch count (n_vol*%d + n_imp) + 4 B/pixel; the 32 MiB working set is "
                         "Infinity-Cache resident, so HBM traffic << algorithmic bytes (DESIGN.md)" % b_vol,

@@ -7,15 +7,13 @@ from collections import defaultdict
 
 root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
+for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True) + glob.glob(root + "/pmc*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
         short = "pq" if "pq_kernel" in name else ("v1" if "raymarch_kernel<1" in name else ("v0" if "raymarch_kernel<0" in name else None))
-        if short is None or ", true" in name.split("(")[0].replace("true, false", ""):
-            pass
         if short is None:
             continue
-        if "<true, true" in name or "<1, true" in name or "<0, true" in name:
+        if "<true, true" in name or "<false, true" in name or "<1, true" in name or "<0, true" in name:
             continue   # COUNT variants
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
