@@ -69,7 +69,15 @@ def main():
             tiles.mean(), tiles.max(), marched.mean(), marched.max(), iters.mean(), iters.max(), flushes.mean(), flushes.max()))
         print("totals: tiles %d marched %d iterations %d flushes %d" % (tiles.sum(), marched.sum(), iters.sum(), flushes.sum()))
         print("us per loop iteration (waves with >=10 iterations): %.3f" % ((dur[iters >= 10] / iters[iters >= 10]).mean() / 100))
+        addr_t = (ph[:, 3] & 0xFFFF).astype(np.float64) * 256.0
+        wait_t = (ph[:, 3] >> 16).astype(np.float64) * 256.0
+        ph = ph.copy(); ph[:, 3] = 0
         tick = ph.astype(np.float64) * 16.0          # shader clock ticks
+        print("sample phase split, all waves: address calc %.1f%%  load wait %.1f%%  of sample-phase ticks" % (
+            100.0 * addr_t.sum() / tick[:, 1].sum(), 100.0 * wait_t.sum() / tick[:, 1].sum()))
+        sl = np.argsort(dur)[-16:]
+        print("slowest 16 waves: per iteration: address calc %.0f  load wait %.0f  (sample phase %.0f)" % (
+            addr_t[sl].sum() / iters[sl].sum(), wait_t[sl].sum() / iters[sl].sum(), tick[sl, 1].sum() / iters[sl].sum()))
         tot = tick.sum(axis=0)
         print("phase shares over all waves (shader ticks): leap %.1f%%  sample %.1f%%  flush %.1f%%  setup+store %.1f%%  ; ticks per us of wave time: %.0f" % (
             *(100.0 * tot / tot.sum()), tot.sum() / (dur.sum() / 100.0)))

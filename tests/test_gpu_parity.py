@@ -213,6 +213,17 @@ def test_full_size_properties(oracle, volym_lib):
         assert int(np.abs(u2.astype(np.int32) - u1.astype(np.int32)).max()) <= 1
         f2b, u2b, _ = _render_gpu(ctx, cam, par, 2)
         assert np.array_equal(u2, u2b) and np.array_equal(f2.view(np.uint32), f2b.view(np.uint32))
+        # static view: the second frame re-sorts the work list by measured cost and marches the most expensive
+        # tiles depth-parallel (four lanes per ray); forced here for EVERY marched tile as well (threshold 1)
+        for thr in (-1, 1):
+            ctx.set_option(105, thr)
+            ctx.update(cu, pu)
+            for _ in range(3):
+                ctx.compute_pass()
+                ctx.sync()
+                assert np.array_equal(ctx.read_rgba8(), u2), thr
+                assert np.array_equal(ctx.read_rgba32f().view(np.uint32), f2.view(np.uint32)), thr
+        ctx.set_option(105, -1)
         f1, u1 = f2, u2
         # (c) oracle on every 8th row
         vol_o, imp_o = common.oracle_scene(oracle, raw, labels, common.BONSAI_SEGMENTS, dims)

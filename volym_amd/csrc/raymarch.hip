@@ -69,6 +69,7 @@ struct volym_ctx {
     uint32_t frames_since_change = 0;
     bool order_by_cost = false;    // d_order currently reflects measured cost
     bool feedback = true;
+    int dp_min_cost = -1;          // measured tile cost from which a tile is marched depth-parallel (0 = never, < 0 = adaptive)
     uint32_t n_items = 0;
     bool order_dirty = true;
     int n_cus = 256;
@@ -222,6 +223,11 @@ int volym_set_option(volym_ctx* c, int key, int value)
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, VOLYM_E_INVALID, "speculation depth: 1, 2, 4 or 8");
         c->kspec = value;
         return VOLYM_OK;
+    case 105:   // undocumented: measured cost from which tiles are marched depth-parallel (0 = never)
+        if (value < -1 || value > 65535) return fail(c, VOLYM_E_INVALID, "dp cost threshold: -1 (adaptive), 0 (off) .. 65535");
+        c->dp_min_cost = value;
+        c->order_dirty = true;
+        return VOLYM_OK;
     case 104:   // undocumented: 0 disables the cost-feedback reordering of variant 2 (A/B tests)
         c->feedback = value != 0;
         c->order_dirty = true;
@@ -253,14 +259,24 @@ static int upload_volume(volym_ctx* c, uint8_t** dst, const uint8_t* src, uint32
 {
     if (!src || nx == 0 || ny == 0 || nz == 0) return fail(c, VOLYM_E_INVALID, "volume: NULL data or zero dimension");
     const uint64_t n = static_cast<uint64_t>(nx) * ny * nz;
-    if (nx > 4096 || ny > 4096 || nz > 4096 || n > 0xffffffffull)
-        return fail(c, VOLYM_E_INVALID, "volume: each dimension <= 4096 and nx*ny*nz < 2^32");
+    const uint64_t nb = VOLYM_BRICKED ? static_cast<uint64_t>(brick_count(nx)) * brick_count(ny) * brick_count(nz) * 64u : n;
+    if (nx > 4096 || ny > 4096 || nz > 4096 || nb > 0xffffffffull)
+        return fail(c, VOLYM_E_INVALID, "volume: each dimension <= 4096 and the brick-padded size < 2^32");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (*dst) { HIPCHK(c, hipFree(*dst)); *dst = nullptr; }
-    hipError_t e = hipMalloc(dst, n);
-    if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(volume): ") + hipGetErrorString(e));
-    HIPCHK(c, hipMemcpy(*dst, src, n, hipMemcpyHostToDevice));
+    uint8_t* staging = nullptr;
+    hipError_t e = hipMalloc(dst, nb);
+    if (e == hipSuccess) e = hipMalloc(&staging, n);
+    if (e != hipSuccess) { (void)hipFree(staging); return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(volume): ") + hipGetErrorString(e)); }
+    e = hipMemcpy(VOLYM_BRICKED ? staging : *dst, src, n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && VOLYM_BRICKED) {
+        hipLaunchKernelGGL(volym_rebrick_kernel, dim3(static_cast<uint32_t>((nb + 255u) / 256u)), dim3(256), 0, c->stream, staging, *dst, nx, ny, nz);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(staging);
+    if (e != hipSuccess) return fail(c, VOLYM_E_HIP, std::string("volume upload: ") + hipGetErrorString(e));
     return VOLYM_OK;
 }
 
@@ -372,7 +388,7 @@ static int build_order(volym_ctx* c)
     if (c->d_cost) { HIPCHK(c, hipFree(c->d_cost)); c->d_cost = nullptr; }
     c->n_items = static_cast<uint32_t>(order.size());
     if (c->n_items) {
-        hipError_t e = hipMalloc(&c->d_order, order.size() * sizeof(uint32_t));
+        hipError_t e = hipMalloc(&c->d_order, order.size() * 4 * sizeof(uint32_t));   // room for quarter-tile items
         if (e == hipSuccess) e = hipMalloc(&c->d_cost, static_cast<size_t>(c->n_local) * 4 * sizeof(uint16_t));
         if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(order): ") + hipGetErrorString(e));
         HIPCHK(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -397,8 +413,29 @@ static int reorder_by_cost(volym_ctx* c)
     std::vector<uint16_t> cost(static_cast<size_t>(c->n_local) * 4);
     HIPCHK(c, hipMemcpyAsync(cost.data(), c->d_cost, cost.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<uint32_t> order = c->h_order;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    // Tiles above dp_min_cost are split into four 4x4 quarter tiles marched depth-parallel (raymarch_pq.h):
+    // their cost is a long chain of dependent samples, which four lanes per ray walk ~4x faster, on four waves.
+    // Which tiles?  Those that would keep one wave busy for more than about twice a wave's fair share of the
+    // frame (sum of costs / resident waves): below that they hide in the bulk and splitting only adds work.
+    uint64_t total_cost = 0;
+    for (uint32_t item : c->h_order) total_cost += cost[item];
+    const uint32_t resident_waves = static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu * PQ_WAVES;
+    const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(64, 2 * total_cost / std::max(1u, resident_waves) + 16));
+    const uint32_t dp_thr = c->dp_min_cost < 0 ? adaptive : static_cast<uint32_t>(c->dp_min_cost);
+    const bool dp_ok = c->dp_min_cost != 0 && !(c->fp.flags & (F_LINEAR | F_GAUSSIAN | F_IMP_RENDERING));
+    std::vector<std::pair<uint32_t, uint32_t>> keyed;      // (cost share, item)
+    keyed.reserve(c->h_order.size() * 2);
+    for (uint32_t item : c->h_order) {
+        const uint32_t k = cost[item];
+        if (dp_ok && k >= dp_thr)
+            for (uint32_t qd = 0; qd < 4; ++qd) keyed.emplace_back((k + 3u) / 4u, 0x80000000u | (item << 2) | qd);
+        else
+            keyed.emplace_back(k, item);
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first > b.first; });
+    std::vector<uint32_t> order(keyed.size());
+    for (size_t i = 0; i < keyed.size(); ++i) order[i] = keyed[i].second;
+    c->n_items = static_cast<uint32_t>(order.size());
     HIPCHK(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->order_by_cost = true;
     return VOLYM_OK;
@@ -789,6 +826,18 @@ int volym_stats_pass(volym_ctx* c, volym_stats* out)
     }
     out->n_rays = rays;
     return VOLYM_OK;
+}
+
+// Development aid: per-item costs (uint16) of the last measuring launch; out needs 4 * n_local entries.
+int volym_dev_read_costs(volym_ctx* c, uint16_t* out, uint32_t max_items)
+{
+    if (!c || !out || !c->d_cost) return VOLYM_E_INVALID;
+    const uint32_t n = c->n_local * 4u;
+    if (max_items < n) return VOLYM_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_cost, n * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return static_cast<int>(n);
 }
 
 // Development aid (not declared in the public header): one instrumented launch that records, per

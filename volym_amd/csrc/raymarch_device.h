@@ -98,13 +98,44 @@ __device__ __forceinline__ float dot_fast(V3 a, V3 b)
     return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
 }
 
+// Volume layout in HBM.  VOLYM_BRICKED = 1 stores 4x4x4 bricks of 64 bytes (brick index x fastest, then y,
+// then z; inside a brick x fastest).  Measured on the bench workload (round 1): no gain -- the march is
+// bound by instruction issue and dependent latency, not by L2 misses -- and ~10 extra integer
+// instructions per address, so the default is the linear layout x + nx*(y + ny*z).
+#ifndef VOLYM_BRICKED
+#define VOLYM_BRICKED 0
+#endif
+__host__ __device__ inline uint32_t brick_count(uint32_t n) { return (n + 3u) >> 2; }
+
 struct Grid {
     const uint8_t* __restrict__ vol;
     const uint8_t* __restrict__ imp;
     int nx, ny, nz;
+    uint32_t bx, bxy;         // bricks per row, bricks per slab
     float fnx, fny, fnz;      // (float)n
     float hix, hiy, hiz;      // (float)(n - 1)
 };
+
+// bx, bxy: bricks per row / per slab (bricked) or nx, nx*ny (linear)
+__host__ __device__ inline uint32_t bricked_offset(uint32_t bx, uint32_t bxy, uint32_t ix, uint32_t iy, uint32_t iz)
+{
+#if VOLYM_BRICKED
+    return (((iz >> 2) * bxy + (iy >> 2) * bx + (ix >> 2)) << 6) | ((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u);
+#else
+    return ix + bx * iy + bxy * iz;
+#endif
+}
+__host__ __device__ inline uint32_t layout_bx(uint32_t nx) { return VOLYM_BRICKED ? brick_count(nx) : nx; }
+__host__ __device__ inline uint32_t layout_bxy(uint32_t nx, uint32_t ny) { return VOLYM_BRICKED ? brick_count(nx) * brick_count(ny) : nx * ny; }
+
+__device__ __forceinline__ void grid_init(Grid& g, const uint8_t* vol, const uint8_t* imp, uint32_t nx, uint32_t ny, uint32_t nz)
+{
+    g.vol = vol; g.imp = imp;
+    g.nx = static_cast<int>(nx); g.ny = static_cast<int>(ny); g.nz = static_cast<int>(nz);
+    g.bx = layout_bx(nx); g.bxy = layout_bxy(nx, ny);
+    g.fnx = static_cast<float>(nx); g.fny = static_cast<float>(ny); g.fnz = static_cast<float>(nz);
+    g.hix = static_cast<float>(nx - 1u); g.hiy = static_cast<float>(ny - 1u); g.hiz = static_cast<float>(nz - 1u);
+}
 
 // nearest filter + ClampToEdge: i = clamp(floor(u * n), 0, n - 1)  (EXACT)
 __device__ __forceinline__ int texel_nearest(float u, float fn, float hi)
@@ -116,8 +147,7 @@ __device__ __forceinline__ int texel_nearest(float u, float fn, float hi)
 
 __device__ __forceinline__ uint32_t voxel_offset(const Grid& g, int ix, int iy, int iz)
 {
-    return static_cast<uint32_t>(ix) +
-           static_cast<uint32_t>(g.nx) * (static_cast<uint32_t>(iy) + static_cast<uint32_t>(g.ny) * static_cast<uint32_t>(iz));
+    return bricked_offset(g.bx, g.bxy, static_cast<uint32_t>(ix), static_cast<uint32_t>(iy), static_cast<uint32_t>(iz));
 }
 
 __device__ __forceinline__ uint32_t nearest_offset(const Grid& g, V3 p)

@@ -162,10 +162,7 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
     const bool in_frame = gx < fp.W && gy < fp.H;   // wgsl:217-219
 
     Grid g;
-    g.vol = vol; g.imp = imp;
-    g.nx = static_cast<int>(fp.nx); g.ny = static_cast<int>(fp.ny); g.nz = static_cast<int>(fp.nz);
-    g.fnx = static_cast<float>(fp.nx); g.fny = static_cast<float>(fp.ny); g.fnz = static_cast<float>(fp.nz);
-    g.hix = static_cast<float>(fp.nx - 1u); g.hiy = static_cast<float>(fp.ny - 1u); g.hiz = static_cast<float>(fp.nz - 1u);
+    grid_init(g, vol, imp, fp.nx, fp.ny, fp.nz);
 
     uint32_t n_vol = 0, n_imp = 0, n_steps = 0, n_dense = 0, n_hit = 0;
     float out_r = 0.0f, out_g = 0.0f, out_b = 0.0f, out_a = 1.0f;   // miss: (0,0,0,1) wgsl:239
@@ -380,7 +377,7 @@ __global__ __launch_bounds__(256) void volym_macrocell_kernel(const uint8_t* __r
     uint32_t m = 0;
     for (uint32_t i = threadIdx.x; i < total; i += 256u) {
         const uint32_t x = x0 + i % wx, y = y0 + (i / wx) % wy, z = z0 + i / (wx * wy);
-        const uint32_t v = vol[static_cast<size_t>(x) + static_cast<size_t>(nx) * (y + static_cast<size_t>(ny) * z)];
+        const uint32_t v = vol[bricked_offset(layout_bx(nx), layout_bxy(nx, ny), x, y, z)];
         m = v > m ? v : m;
     }
     for (int s = 32; s > 0; s >>= 1) { const uint32_t o = __shfl_xor(m, s, 64); m = o > m ? o : m; }
@@ -392,6 +389,21 @@ __global__ __launch_bounds__(256) void volym_macrocell_kernel(const uint8_t* __r
         for (int w = 1; w < 4; ++w) r = s_m[w] > r ? s_m[w] : r;
         mc_max[cell] = static_cast<uint8_t>(r);
     }
+}
+
+// linear (x fastest) staging copy -> 4x4x4 bricks; one thread per voxel of the padded grid
+__global__ __launch_bounds__(256) void volym_rebrick_kernel(const uint8_t* __restrict__ linear, uint8_t* __restrict__ bricked,
+                                                            uint32_t nx, uint32_t ny, uint32_t nz)
+{
+    const uint32_t bx = brick_count(nx), by = brick_count(ny), bz = brick_count(nz);
+    const uint64_t total = static_cast<uint64_t>(bx) * by * bz * 64u;
+    const uint64_t o = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    if (o >= total) return;
+    const uint32_t brick = static_cast<uint32_t>(o >> 6), in = static_cast<uint32_t>(o & 63u);
+    const uint32_t x = (brick % bx) * 4u + (in & 3u), y = ((brick / bx) % by) * 4u + ((in >> 2) & 3u), z = (brick / (bx * by)) * 4u + (in >> 4);
+    uint8_t v = 0;
+    if (x < nx && y < ny && z < nz) v = linear[static_cast<size_t>(x) + static_cast<size_t>(nx) * (y + static_cast<size_t>(ny) * z)];
+    bricked[o] = v;
 }
 
 // root side of the image gather: world shards of 16x16 tiles -> W x H raster

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     constexpr int K = TABLE ? KSPEC : 1;     // speculation depth
     unsigned long long trace_t0 = 0;
     uint32_t trace_iters = 0, trace_flushes = 0, trace_tiles = 0, trace_marched = 0;
-    unsigned long long tm_leap = 0, tm_samp = 0, tm_flush = 0, tm_setup = 0, tm_mark = 0;
+    unsigned long long tm_leap = 0, tm_samp = 0, tm_flush = 0, tm_setup = 0, tm_mark = 0, tm_addr = 0, tm_wait = 0;
 #define PQ_TICK() (TRACE ? __builtin_amdgcn_s_memtime() : 0ull)
     if (TRACE) trace_t0 = __builtin_amdgcn_s_memrealtime();
 
@@ -131,10 +131,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     Grid g;
-    g.vol = vol; g.imp = imp;
-    g.nx = static_cast<int>(fp.nx); g.ny = static_cast<int>(fp.ny); g.nz = static_cast<int>(fp.nz);
-    g.fnx = static_cast<float>(fp.nx); g.fny = static_cast<float>(fp.ny); g.fnz = static_cast<float>(fp.nz);
-    g.hix = static_cast<float>(fp.nx - 1u); g.hiy = static_cast<float>(fp.ny - 1u); g.hiz = static_cast<float>(fp.nz - 1u);
+    grid_init(g, vol, imp, fp.nx, fp.ny, fp.nz);
 
     float* const qx = s_qx[wave];
     float* const qy = s_qy[wave];
@@ -161,18 +158,30 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     const bool culling = !COUNT && fp.cull != 0u;
     for (uint32_t ticket = grab(); ticket < n_mine; ticket = grab()) {
       {
-        const uint32_t item = __builtin_amdgcn_readfirstlane(order[blockIdx.x + static_cast<size_t>(gridDim.x) * ticket]);
+        // item = local_tile*4 + sub (an 8x8 wave tile, one lane per ray), or, for tiles the cost feedback
+        // found expensive, bit 31 | (that id << 2) | quarter: a 4x4 quarter tile marched DEPTH-PARALLEL,
+        // four lanes per ray, lane k of a quad taking the k-th speculative sample (see "dp" below)
+        const uint32_t raw = __builtin_amdgcn_readfirstlane(order[blockIdx.x + static_cast<size_t>(gridDim.x) * ticket]);
+        const bool is_quarter = (raw >> 31) != 0u;
+        const bool dp = is_quarter && TABLE && !COUNT;
+        const uint32_t item = is_quarter ? ((raw & 0x7fffffffu) >> 2) : raw;
+        const uint32_t quarter = raw & 3u;
+        if (is_quarter && !dp && quarter != 0u) continue;   // instrumented launch: quarter 0 stands for the whole tile
         const uint32_t local_tile = item >> 2, sub = item & 3u;
         const uint32_t tile = local_tile * fp.world + fp.rank;
         const uint32_t tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
-        const uint32_t gx = tx * 16u + ((sub & 1u) << 3) + (lane & 7u);
-        const uint32_t gy = ty * 16u + ((sub >> 1) << 3) + (lane >> 3);
+        const uint32_t px_in_sub = dp ? (((quarter & 1u) << 2) + ((lane >> 2) & 3u)) : (lane & 7u);
+        const uint32_t py_in_sub = dp ? (((quarter >> 1) << 2) + (lane >> 4)) : (lane >> 3);
+        const uint32_t sub_lane = py_in_sub * 8u + px_in_sub;       // position inside the 8x8 sub-tile
+        const uint32_t own = dp ? (lane & ~3u) : lane;              // lane whose accumulators this ray uses
+        const uint32_t gx = tx * 16u + ((sub & 1u) << 3) + px_in_sub;
+        const uint32_t gy = ty * 16u + ((sub >> 1) << 3) + py_in_sub;
         const bool in_frame = gx < fp.W && gy < fp.H;   // wgsl:217-219
 
         if (TRACE) { trace_tiles++; tm_mark = PQ_TICK(); }
         uint32_t tile_iters = 0, tile_flushes = 0;      // measured cost of this tile, fed back to the scheduler
         uint32_t tclass = TILE_MARCH;
-        if (culling) {
+        if (culling && !dp) {
             tclass = classify_tile(fp, lane, static_cast<float>(tx * 16u + ((sub & 1u) << 3)), static_cast<float>(ty * 16u + ((sub >> 1) << 3)));
             if (tclass >= TILE_FILL_EMPTY) {            // no ray of this tile can differ from the constant
                 const uint32_t packed = tclass == TILE_FILL_MISS ? 0xff000000u : 0u;     // (0,0,0,1) wgsl:239 / (0,0,0,0) wgsl:328
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         if (flags & F_WRITE_F32) out_f32[o] = make_float4(0.0f, 0.0f, 0.0f, tclass == TILE_FILL_MISS ? 1.0f : 0.0f);
                     }
                 } else {
-                    out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + lane] = in_frame ? packed : 0u;
+                    out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + sub_lane] = in_frame ? packed : 0u;
                 }
                 if (cost && lane == 0) cost[item] = 0;
                 continue;
@@ -305,10 +314,9 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         };
 
         if (TRACE) { const unsigned long long now = PQ_TICK(); tm_setup += now - tm_mark; tm_mark = now; }
-        while (__ballot(active) != 0ull) {
-            tile_iters++;
-            if (TRACE) { trace_iters++; tm_mark = PQ_TICK(); }
-            // ---- 1. at most ONE leap per lane and iteration through provably empty macro cells (see
+        // ---- at most ONE leap per lane and iteration through provably empty macro cells (both march paths) ----
+        auto leap_phase = [&]() {
+            // at most ONE leap per lane and iteration through provably empty macro cells (see
             // raymarch_kernels.h VARIANT 1).  Cells with distance value < PQ_MIN_LEAP_D are simply sampled:
             // a one-cell leap replays ~3 steps, which the K-wide speculation below covers in the same
             // iteration without the ~100 instructions and the LDS round trip of a leap. ----
@@ -347,6 +355,96 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 }
             }
 
+        };
+
+        if (dp) {
+            // ================= depth-parallel march of a 4x4 quarter tile =================
+            // Lanes 4r..4r+3 hold the same ray r; lane k of the quad takes the k-th of the four speculative
+            // samples.  All state (t, cur, alpha, last_dense) is replicated in the quad and updated by the
+            // same arithmetic in every lane, so the accepted samples are those of the sequential march.
+            const uint32_t kq = lane & 3u, qsh = lane & 60u;
+            const bool use_alpha_dp = imp_coloring || (flags & F_OPACITY) != 0u;
+            while (__ballot(active) != 0ull) {
+                tile_iters++;
+                if (TRACE) { trace_iters++; tm_mark = PQ_TICK(); }
+                leap_phase();
+                if (TRACE) { const unsigned long long now = PQ_TICK(); tm_leap += now - tm_mark; tm_mark = now; }
+                // positions of the four speculative samples under "class stays last_dense" (wgsl:263-274)
+                float ts4[4], cs4[4];
+                {
+                    float tt = t, cc = cur;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ts4[j] = tt;
+                        cc = last_dense ? min_step : __builtin_fminf(base, cc * 1.5f);
+                        cs4[j] = cc;
+                        tt += cc;
+                    }
+                }
+                const float tk = kq == 0u ? ts4[0] : (kq == 1u ? ts4[1] : (kq == 2u ? ts4[2] : ts4[3]));
+                const V3 pos = ray.o + ray.d * tk;                    // wgsl:251
+                const uint32_t off = nearest_offset(g, pos);
+                uint32_t b = 0, ib = 0;
+                if (active) {
+                    b = vol[off];
+                    if (need_imp) ib = imp[off];
+                }
+                const bool dense_k = b >= fp.thr_byte;                // <=> b/255 >= thr
+                const float a_k = imp_coloring ? s_ic_alpha[ib] : s_tf_tab[b].w;
+                const uint32_t quad_d = static_cast<uint32_t>(__ballot(dense_k) >> qsh) & 15u;
+                const uint32_t quad_c = static_cast<uint32_t>(__ballot(tk < t_end) >> qsh) & 15u;
+                const int a_bits = __float_as_int(a_k);
+                const float a4[4] = {__int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0x00, 0xf, 0xf, true)),
+                                     __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0x55, 0xf, 0xf, true)),
+                                     __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0xaa, 0xf, 0xf, true)),
+                                     __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0xff, 0xf, 0xf, true))};
+                // accept samples in order with their real classes; identical in the four lanes
+                float alpha = acc_a, my_w = 0.0f;
+                bool my_emit = false, done = false, finished = false;
+                int last = -1;
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!done) {
+                            if (!(((quad_c >> j) & 1u) != 0u && alpha < 0.95f)) {      // wgsl:250
+                                done = true; finished = true;
+                            } else {
+                                const bool dj = ((quad_d >> j) & 1u) != 0u;
+                                last = j;
+                                if (dj) {
+                                    if (use_alpha_dp) {                               // wgsl:313-318
+                                        const float w = (1.0f - alpha) * a4[j];
+                                        if (static_cast<uint32_t>(j) == kq) { my_w = w; my_emit = true; }
+                                        alpha += w;
+                                    } else {                                          // wgsl:319-323
+                                        if (static_cast<uint32_t>(j) == kq) { my_w = 1.0f; my_emit = true; }
+                                        alpha = 1.0f;
+                                        done = true; finished = true;
+                                    }
+                                }
+                                if (dj != last_dense) done = true;                    // later positions are off
+                            }
+                        }
+                    }
+                    if (last >= 0) {
+                        const bool dl = ((quad_d >> last) & 1u) != 0u;
+                        const float cur_before = last == 0 ? cur : (last == 1 ? cs4[0] : (last == 2 ? cs4[1] : cs4[2]));
+                        const float t_last = last == 0 ? ts4[0] : (last == 1 ? ts4[1] : (last == 2 ? ts4[2] : ts4[3]));
+                        cur = dl ? min_step : __builtin_fminf(base, cur_before * 1.5f);   // wgsl:263-269 with the real class
+                        if (!(finished && !use_alpha_dp && dl)) t = t_last + cur;         // wgsl:272, :325 (not after the first-hit break)
+                        last_dense = dl;
+                    }
+                    acc_a = alpha;
+                    if (finished) active = false;
+                }
+                append(my_emit, pos, my_w, own | (b << 8) | (ib << 16), 0.0f);
+                if (TRACE) tm_samp += PQ_TICK() - tm_mark;
+            }
+        } else {
+        while (__ballot(active) != 0ull) {
+            tile_iters++;
+            if (TRACE) { trace_iters++; tm_mark = PQ_TICK(); }
+            leap_phase();
             if (TRACE) { const unsigned long long now = PQ_TICK(); tm_leap += now - tm_mark; tm_mark = now; }
             // ---- 2. K speculative samples: positions under the prediction "class stays last_dense" ----
             float ts[K];
@@ -362,6 +460,8 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                     cc = last_dense ? min_step : __builtin_fminf(base, cc * 1.5f);
                     tt += cc;
                 }
+                unsigned long long ta = 0;
+                if (TRACE) { ta = PQ_TICK(); tm_addr += ta - tm_mark; }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     bs[k] = 0; ibs[k] = 0; rhos[k] = 0.0f;
@@ -370,6 +470,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         if (need_imp) ibs[k] = imp[offs[k]];
                     }
                 }
+                if (TRACE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tm_wait += PQ_TICK() - ta; }
             }
 
             // ---- 3. accept samples in order with their real classes ----
@@ -431,28 +532,29 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                     }
                     if (advance) t += cur;                        // wgsl:272, :292, :325
                 }
-                append(emit, pos, w, lane | (bs[k] << 8) | (ibs[k] << 16), rhos[k]);
+                append(emit, pos, w, own | (bs[k] << 8) | (ibs[k] << 16), rhos[k]);
             }
             if (TRACE) tm_samp += PQ_TICK() - tm_mark;
+        }
         }
         if (q_count) flush(q_count);
 
         // ---- store (wgsl:328-329; rgba8unorm) ----
-        if (in_frame) {
-            const float out_r = static_cast<float>(acc_r[lane]) * PQ_FIX_INV, out_g = static_cast<float>(acc_g[lane]) * PQ_FIX_INV,
-                        out_b = static_cast<float>(acc_b[lane]) * PQ_FIX_INV;
+        if (in_frame && (!dp || (lane & 3u) == 0u)) {
+            const float out_r = static_cast<float>(acc_r[own]) * PQ_FIX_INV, out_g = static_cast<float>(acc_g[own]) * PQ_FIX_INV,
+                        out_b = static_cast<float>(acc_b[own]) * PQ_FIX_INV;
             const uint32_t packed = pack_rgba8(out_r, out_g, out_b, acc_a);
             if (flags & F_RASTER) {
                 const size_t o = static_cast<size_t>(gy) * fp.W + gx;
                 out_raster[o] = packed;
                 if (flags & F_WRITE_F32) out_f32[o] = make_float4(out_r, out_g, out_b, acc_a);
             } else {
-                out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + lane] = packed;
+                out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + sub_lane] = packed;
             }
-        } else if (!(flags & F_RASTER)) {
-            out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + lane] = 0u;
+        } else if (!in_frame && !(flags & F_RASTER) && (!dp || (lane & 3u) == 0u)) {
+            out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + sub_lane] = 0u;
         }
-        if (cost && lane == 0) cost[item] = static_cast<uint16_t>(min(65535u, 1u + tile_iters * 8u + tile_flushes * 3u));
+        if (cost && !dp && lane == 0) cost[item] = static_cast<uint16_t>(min(65535u, 1u + tile_iters * 8u + tile_flushes * 3u));
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
@@ -462,7 +564,8 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
         const size_t rec = (static_cast<size_t>(blockIdx.x) * PQ_WAVES + wave) * 2u;
         trace[rec] = make_uint4(static_cast<uint32_t>(trace_t0), static_cast<uint32_t>(t1 - trace_t0), trace_iters | (trace_tiles << 16), trace_flushes | (trace_marched << 16));
-        trace[rec + 1] = make_uint4(static_cast<uint32_t>(tm_leap >> 4), static_cast<uint32_t>((tm_samp - tm_flush) >> 4), static_cast<uint32_t>(tm_flush >> 4), static_cast<uint32_t>(tm_setup >> 4));
+        trace[rec + 1] = make_uint4(static_cast<uint32_t>(tm_leap >> 4), static_cast<uint32_t>((tm_samp - tm_flush) >> 4), static_cast<uint32_t>(tm_flush >> 4),
+                                    (static_cast<uint32_t>(tm_addr >> 8) & 0xffffu) | (static_cast<uint32_t>(tm_wait >> 8) << 16));
     }
     if (COUNT) {
         unsigned long long v[5] = {n_vol, n_imp, n_steps, n_dense, n_hit};
