@@ -32,9 +32,14 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def build_scene(args):
     from volym_amd import scene, synth
     n = args.volume
-    raw, labels = synth.synth_bonsai(n, with_labels=True)
-    segments = [{"label_value": 2, "importance": 255}, {"label_value": 3, "importance": 0},
-                {"label_value": 4, "importance": 0}]
+    if args.teapot:      # the reference's default dataset, 256x256x178 zero-padded to 256^3 (src/gpu_resources/volume.rs:40-55)
+        raw, labels = synth.synth_teapot()
+        segments = synth.TEAPOT_SEGMENTS
+        n = 256
+    else:
+        raw, labels = synth.synth_bonsai(n, with_labels=True)
+        segments = [{"label_value": 2, "importance": 255}, {"label_value": 3, "importance": 0},
+                    {"label_value": 4, "importance": 0}]
     dims = (n, n, n)
     volume = scene.prepare_volume(raw, dims, True)
     importances = scene.prepare_volume(scene.map_segments_to_importance(labels, segments), dims, True)
@@ -97,7 +102,20 @@ def main():
     ap.add_argument("--cone", action="store_true")
     ap.add_argument("--xcd-bands", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configs[0..4] presets (default = c3, the configuration the metric is quoted on): "
+                         "c1 teapot 512x512, c2 bonsai 1080p direct kernel, c3 bonsai 1080p, c4 bonsai 4K, c5 synthetic 1024^3 + labels 4K importance")
     args = ap.parse_args()
+    if args.workload == "c1":
+        args.width = args.height = 512
+        args.teapot = True
+    elif args.workload == "c2":
+        args.kernel = 0
+    elif args.workload == "c4":
+        args.width, args.height = 3840, 2160
+    elif args.workload == "c5":
+        args.width, args.height, args.volume, args.importance = 3840, 2160, 1024, True
+    args.teapot = getattr(args, "teapot", False)
 
     import torch
     import torch.distributed as dist
@@ -233,10 +251,10 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u8 voxels, f32 compositing",
-            "data": "synthetic (volym_amd.synth.synth_bonsai(%d), seed 20250310)" % args.volume,
+            "data": "synthetic (volym_amd.synth.%s, seed 20250310)" % ("synth_teapot()" if args.teapot else "synth_bonsai(%d)" % args.volume),
             "config": {
-                "workload": "bonsai %d^3 uint8 @ %dx%d, %s filter, step %g, thr 0.15, opacity on%s, kernel=%s (BASELINE configs[%d])"
-                            % (args.volume, W, H, "linear" if args.linear else "nearest (reference parity)", args.step,
+                "workload": ("teapot 256x256x178->256^3" if args.teapot else "bonsai %d^3" % args.volume) + " uint8 @ %dx%d, %s filter, step %g, thr 0.15, opacity on%s, kernel=%s (BASELINE configs[%d])"
+                            % (W, H, "linear" if args.linear else "nearest (reference parity)", args.step,
                                ", importance look-ahead %s" % ("cone" if args.cone else "straight") if args.importance else "",
                                {0: "direct", 1: "macro-cell", 2: "persistent+LDS-staged+queue"}[args.kernel], 1 if args.kernel == 0 else 2),
                 "viewport": [W, H], "volume": list(dims), "tile_sharding": "interleaved 16x16 tiles, k %% %d" % world,

@@ -118,6 +118,12 @@ int volym_prepare_volume(const uint8_t* raw, size_t len, uint32_t nx, uint32_t n
 int volym_map_segments_to_importance(uint8_t* data, size_t len, const uint8_t* label_values,
                                      const uint8_t* importances, uint32_t n_segments);
 
+/* Deterministic stand-ins for the reference's undistributed .raw assets (.MISSING_LARGE_BLOBS:1-4), byte for byte
+ * what volym_amd/synth.py generates: synth_bonsai(n) (labels may be NULL) and synth_teapot(nx, ny, nz)
+ * (labels carry the label_values of assets/boston_teapot_256x256x178_uint8_segments.json).  Files "as on disk". */
+int volym_synth_bonsai(uint32_t n, uint32_t seed, uint8_t* density, uint8_t* labels);
+int volym_synth_teapot(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, uint8_t* density, uint8_t* labels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -379,3 +379,53 @@ def test_shard_layout_matches_host_mirror(oracle, volym_lib):
                 root.sync()
                 assert np.array_equal(root.read_rgba8(), full)
             assert np.array_equal(sharding.assemble(np.concatenate(shards), W, H, world), full)
+
+
+def test_cli_benchmark_and_run(volym_lib, tmp_path):
+    """`python -m volym_amd benchmark` writes the reference's 28-row CSV (src/main.rs:71-85, :178-345);
+    `run simple` writes the screenshot PNG of the interactive default view."""
+    import csv
+    from volym_amd import __main__ as cli, image
+    out = str(tmp_path / "benchmark_results.csv")
+    assert cli.main(["benchmark", "--width", "192", "--height", "144", "--secs", "0.002", "--output", out]) == 0
+    rows = list(csv.DictReader(open(out)))
+    assert len(rows) == 28 and list(rows[0].keys())[:12] == cli.CSV_COLUMNS
+    assert [r["algorithm"] for r in rows].count("ImportanceCone") == 12
+    assert all(float(r["avg_fps"]) > 0 and float(r["b_alg_bytes_per_frame"]) > 0 for r in rows)
+    shot = str(tmp_path / "shot.png")
+    assert cli.main(["run", "simple", "--width", "160", "--height", "90", "--screenshot", shot]) == 0
+    img = image.read_png_rgba8(shot)
+    assert img.shape == (90, 160, 4) and img[..., :3].any()
+
+
+def test_cpp_cli_binary(volym_lib, tmp_path):
+    """The compiled host side: `volym benchmark` / `volym run simple` (C++ ComputeDemo/Simple over the C ABI)
+    give the CSV schema of the reference and the same frame as the Python mirror."""
+    import csv
+    import os
+    import subprocess
+    from volym_amd import _lib, demo, scene, synth
+    exe = os.path.join(os.path.dirname(_lib.LIB_PATH), "volym")
+    assert os.path.exists(exe), "build with make -C volym_amd/csrc"
+    out = str(tmp_path / "bench.csv")
+    r = subprocess.run([exe, "benchmark", "--width", "192", "--height", "144", "--secs", "0.002", "--output", out],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = list(csv.DictReader(open(out)))
+    assert len(rows) == 28 and rows[0]["algorithm"] == "Base" and rows[27]["use_cone"] == "true"
+    ppm = str(tmp_path / "frame.ppm")
+    r = subprocess.run([exe, "run", "simple", "--width", "160", "--height", "90", "--output", ppm], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    data = open(ppm, "rb").read()
+    header = b"P6\n160 90\n255\n"
+    assert data.startswith(header)
+    rgb = np.frombuffer(data[len(header):], np.uint8).reshape(90, 160, 3)
+    # the Python mirror of the same view
+    raw, labels = synth.synth_teapot()
+    state = scene.State.with_parameters(160 / 90, scene.StateParameters())
+    state.update()
+    with demo.GpuContext(160, 90, 0) as ctx:
+        d = demo.Simple.init(ctx, state, volume_raw=raw, labels_raw=labels, segments=synth.TEAPOT_SEGMENTS)
+        d.compute_pass(ctx)
+        ctx.sync()
+        assert np.array_equal(ctx.read_rgba8()[..., :3], rgb)

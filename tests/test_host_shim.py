@@ -148,3 +148,25 @@ def test_sharding_mirror_roundtrip():
             shards = [sharding.pack_shard(frame, r, world) for r in range(world)]
             assert all(s.size == sharding.shard_bytes(W, H, world) for s in shards)
             assert np.array_equal(sharding.assemble(np.concatenate(shards), W, H, world), frame)
+
+
+def test_png_roundtrip(tmp_path):
+    from volym_amd import image
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, (13, 29, 4), dtype=np.uint8)
+    p = str(tmp_path / "x.png")
+    image.write_png(p, a)
+    assert np.array_equal(image.read_png_rgba8(p), a)
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(p).convert("RGBA")), a)
+
+
+def test_benchmark_sweep_rows_match_reference():
+    """28 rows in the reference's order and naming (src/main.rs:192-335), CSV header of src/main.rs:71-85."""
+    from volym_amd import __main__ as cli
+    rows = cli.sweep_rows()
+    assert len(rows) == 28
+    assert rows[0] == ("Base", 0.003, 0, False) and rows[3] == ("Base", 0.02, 0, False)
+    assert rows[4] == ("Importance", 0.003, 10, False) and rows[15] == ("Importance", 0.02, 20, False)
+    assert rows[16] == ("ImportanceCone", 0.003, 10, True) and rows[27] == ("ImportanceCone", 0.02, 20, True)
+    assert cli.CSV_COLUMNS[:4] == ["algorithm", "step_size", "importance_steps", "use_cone"] and len(cli.CSV_COLUMNS) == 12

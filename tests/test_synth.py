@@ -29,3 +29,19 @@ def test_bonsai256_and_teapot_hashes():
     assert synth.sha256(d) == "8b9ca080da554f5a0800e8a8c5ed42caedc593ae14fa3fff8abdd54945db4761"
     assert synth.sha256(l) == "c50a55185c5abfcc2036a1626b9fb463f74a8f635dad4bb81ceadbb568756a3a"
     assert set(np.unique(l)) == {0, 2, 3, 4}
+
+
+def test_cpp_generators_match_python(volym_lib):
+    """The C++ generators in libvolym_hip.so (used by the `volym` binary) produce the same bytes."""
+    import ctypes as C
+    u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+    d = np.empty(64 ** 3, np.uint8)
+    l = np.empty(64 ** 3, np.uint8)
+    assert volym_lib.volym_synth_bonsai(64, synth.DEFAULT_SEED, u8(d), u8(l)) == 0
+    pv, pl = synth.synth_bonsai(64, with_labels=True)
+    assert np.array_equal(d, pv) and np.array_equal(l, pl)
+    n = 256 * 256 * 178
+    d, l = np.empty(n, np.uint8), np.empty(n, np.uint8)
+    assert volym_lib.volym_synth_teapot(256, 256, 178, synth.DEFAULT_SEED, u8(d), u8(l)) == 0
+    assert synth.sha256(d) == "8b9ca080da554f5a0800e8a8c5ed42caedc593ae14fa3fff8abdd54945db4761"
+    assert synth.sha256(l) == "c50a55185c5abfcc2036a1626b9fb463f74a8f635dad4bb81ceadbb568756a3a"

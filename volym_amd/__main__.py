@@ -1,0 +1,140 @@
+"""`python -m volym_amd [run simple | benchmark] [-d]` -- the headless counterpart of the reference's CLI
+(`cargo run`, `cargo run -- benchmark`; src/cli.rs:4-56, src/main.rs:42-49).
+
+benchmark: the reference's sweep (src/main.rs:178-345) -- 4 step sizes x {Base, Importance x {10,15,20},
+ImportanceCone x {10,15,20}} = 28 rows, 3 trials each, 1024x768, benchmark parameters -- written to
+benchmark_results.csv with the reference's columns (src/main.rs:71-85) followed by Mrays/s, algorithmic
+bytes/GB/s and the roofline fraction.  Unlike the reference (presented frames over 2 s of wall clock, with
+blit, GUI and possibly vsync inside), a trial here is `--secs` of back-to-back compute passes timed with
+HIP events.  The reference's teapot .raw files are not distributed (.MISSING_LARGE_BLOBS); pass
+--volume/--labels/--segments for real data, otherwise the synthetic stand-in of volym_amd.synth is used.
+
+run simple: renders the interactive default view (src/state.rs:41-55) once and writes screenshot_<unix time>.png
+like the reference's `P` key (src/state.rs:85-113).
+"""
+import argparse
+import csv
+import sys
+import time
+
+import numpy as np
+
+from . import _lib, demo, image, scene, synth
+
+STEP_SIZES = [0.0030, 0.0050, 0.0100, 0.0200]   # src/main.rs:192
+IMPORTANCE_STEPS = [10, 15, 20]                  # src/main.rs:193
+NUM_TRIALS = 3                                   # src/main.rs:179
+CSV_COLUMNS = ["algorithm", "step_size", "importance_steps", "use_cone", "avg_total_frames", "avg_total_time_ms",
+               "avg_frame_time_ms", "avg_fps", "std_dev_total_frames", "std_dev_total_time_ms", "std_dev_frame_time_ms",
+               "std_dev_fps"]                    # src/main.rs:71-85
+EXTRA_COLUMNS = ["mrays_per_s", "b_alg_bytes_per_frame", "algorithmic_gb_per_s", "hbm_roofline_fraction", "n_gpus"]
+
+
+def sweep_rows():
+    """(algorithm, step_size, importance_steps, use_cone) in the reference's order (src/main.rs:197-335)."""
+    rows = [("Base", s, 0, False) for s in STEP_SIZES]
+    rows += [("Importance", s, n, False) for s in STEP_SIZES for n in IMPORTANCE_STEPS]
+    rows += [("ImportanceCone", s, n, True) for s in STEP_SIZES for n in IMPORTANCE_STEPS]
+    return rows
+
+
+def _load_assets(args):
+    if args.volume:
+        raw = np.fromfile(args.volume, np.uint8)
+        labels = np.fromfile(args.labels, np.uint8) if args.labels else np.zeros(0, np.uint8)
+        segments = scene.load_segments(args.segments) if args.segments else []
+        return raw, labels, segments, "file:" + args.volume
+    raw, labels = synth.synth_teapot()
+    return raw, labels, synth.TEAPOT_SEGMENTS, "synthetic teapot 256x256x178 (volym_amd.synth)"
+
+
+def _stats(values):
+    m = float(np.mean(values))
+    return m, float(np.sqrt(np.mean((np.asarray(values, np.float64) - m) ** 2)))   # population std, src/main.rs:124-158
+
+
+def benchmark(args):
+    W, H = args.width, args.height
+    raw, labels, segments, what = _load_assets(args)
+    print("volym benchmark: %s, %dx%d, %d rows x %d trials of %.2f s" % (what, W, H, len(sweep_rows()), NUM_TRIALS, args.secs))
+    base = scene.StateParameters.benchmark()                        # src/main.rs:180-190
+    out_rows = []
+    with demo.GpuContext(W, H, args.device) as ctx:
+        state = scene.State.with_parameters(W / H, base)
+        d = demo.Simple.init(ctx, state, volume_raw=raw, labels_raw=labels, segments=segments, dims=(256, 256, 256))
+        for (algo, step, isteps, cone) in sweep_rows():
+            p = base.replace(raymarching_step_size=step)
+            if algo != "Base":
+                p = p.replace(use_importance_rendering=1, importance_check_ahead_steps=isteps, use_cone_importance_check=1 if cone else 0)
+            state = scene.State.with_parameters(W / H, p)
+            state.update()                                          # src/event_loop.rs:100
+            d.update_gpu_state(ctx, state)
+            ms = ctx.time_passes(8)                                 # warm-up; also sizes the trial
+            per = max(float(np.median(ms)), 1e-3)
+            n = int(min(max(args.secs * 1e3 / per, 4), 20000))
+            frames, times, ftimes, fps = [], [], [], []
+            for _ in range(NUM_TRIALS):
+                ms = ctx.time_passes(n)
+                total = float(ms.sum())
+                frames.append(n); times.append(total); ftimes.append(total / n); fps.append(n / (total * 1e-3))
+            st = ctx.stats_pass()
+            b_alg = st["n_vol"] + st["n_imp"] + 4 * W * H
+            ft = float(np.mean(ftimes))
+            row = [algo, step, isteps, str(cone).lower()]
+            for v in (frames, times, ftimes, fps):
+                row.append(_stats(v)[0])
+            for v in (frames, times, ftimes, fps):
+                row.append(_stats(v)[1])
+            row += [W * H / (ft * 1e-3) / 1e6, b_alg, b_alg / (ft * 1e-3) / 1e9, b_alg / (ft * 1e-3) / 8.0e12, 1]
+            out_rows.append(row)
+            print("%-14s step %.4f steps %2d: %8.3f ms/frame %9.1f fps %9.0f Mrays/s  B_alg %6.1f MB  %5.1f%% of HBM roofline" % (
+                algo, step, isteps, ft, _stats(fps)[0], row[12], b_alg / 1e6, 100 * row[15]), flush=True)
+    with open(args.output, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(CSV_COLUMNS + EXTRA_COLUMNS)
+        w.writerows(out_rows)
+    print("wrote", args.output)
+    return 0
+
+
+def run_simple(args):
+    W, H = args.width, args.height
+    raw, labels, segments, what = _load_assets(args)
+    state = scene.State.with_parameters(W / H, scene.StateParameters())   # interactive defaults, src/state.rs:41-55
+    state.update()
+    with demo.GpuContext(W, H, args.device) as ctx:
+        d = demo.Simple.init(ctx, state, volume_raw=raw, labels_raw=labels, segments=segments, dims=(256, 256, 256))
+        d.update_gpu_state(ctx, state)
+        d.compute_pass(ctx)
+        ctx.sync()
+        frame = ctx.read_rgba8()
+    path = args.screenshot or ("screenshot_%d.png" % int(time.time()))
+    image.write_png(path, frame)
+    print("run simple: %s, %dx%d -> %s" % (what, W, H, path))
+    return 0
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="volym", description="MI355X ray-march path of volym")
+    ap.add_argument("-d", "--debug", action="store_true", help="verbose logging (src/cli.rs:9-11)")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--volume"); ap.add_argument("--labels"); ap.add_argument("--segments")
+    sub = ap.add_subparsers(dest="command")
+    run = sub.add_parser("run", help="run the demo (default)")
+    run.add_argument("demo", nargs="?", default="simple", choices=["simple"])
+    run.add_argument("--width", type=int, default=1280); run.add_argument("--height", type=int, default=720)
+    run.add_argument("--screenshot")
+    b = sub.add_parser("benchmark", help="run benchmarks on all demos")
+    b.add_argument("--width", type=int, default=1024); b.add_argument("--height", type=int, default=768)   # src/main.rs:356-359
+    b.add_argument("--secs", type=float, default=0.25, help="GPU seconds per trial (the reference uses 2 s of wall clock)")
+    b.add_argument("--output", default="benchmark_results.csv")
+    args = ap.parse_args(argv)
+    if args.command == "benchmark":
+        return benchmark(args)
+    if args.command is None:
+        args.width, args.height, args.screenshot = 1280, 720, None
+    return run_simple(args)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -158,6 +158,8 @@ SIGNATURES = {
     "volym_transfer_function_bake": (C.c_int, [_f32p, C.c_uint32, _f32p, C.c_uint32, _u8p]),
     "volym_prepare_volume": (C.c_int, [_u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _u8p]),
     "volym_map_segments_to_importance": (C.c_int, [_u8p, C.c_size_t, _u8p, _u8p, C.c_uint32]),
+    "volym_synth_bonsai": (C.c_int, [C.c_uint32, C.c_uint32, _u8p, _u8p]),
+    "volym_synth_teapot": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _u8p, _u8p]),
 }
 
 _lib = None

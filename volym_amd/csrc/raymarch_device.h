@@ -236,6 +236,12 @@ __device__ __forceinline__ float4 sample_tf(const float4* __restrict__ s_lut, ui
     return make_float4(a.x * iw + b.x * w, a.y * iw + b.y * w, a.z * iw + b.z * w, a.w * iw + b.w * w);
 }
 
+// Look-ahead probes (wgsl:94-160).  The probe positions follow pos += dir*step whatever the fetched values
+// are, so the importance bytes are gathered PQ_PROBE_BATCH at a time (one memory round trip per batch
+// instead of one per probe) and then examined in order: same answer, and the reference-fetch count stops at
+// the probe on which the shader would have returned.
+#define VOLYM_PROBE_BATCH 4
+
 // wgsl:141-160  (EXACT)
 template <bool COUNT>
 __device__ __forceinline__ bool ahead_straight(const Grid& g, const FrameParams& fp, V3 cur, V3 dir, float t_exit,
@@ -244,11 +250,20 @@ __device__ __forceinline__ bool ahead_straight(const Grid& g, const FrameParams&
     V3 pos = cur;
     const int n = static_cast<int>(fp.ahead_steps);
     const float step = (t_exit - length_exact(cur)) / static_cast<float>(n);
-    for (int i = 0; i < n; ++i) {
-        pos = pos + dir * step;
-        const uint32_t ib = g.imp[nearest_offset(g, pos)];
-        if (COUNT) n_imp++;
-        if (ib >= 128u) return true;   // i/255 >= 0.5  <=>  i >= 128
+    for (int i = 0; i < n; i += VOLYM_PROBE_BATCH) {
+        uint32_t ib[VOLYM_PROBE_BATCH];
+#pragma unroll
+        for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
+            pos = pos + dir * step;
+            ib[j] = (i + j < n) ? g.imp[nearest_offset(g, pos)] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
+            if (i + j < n) {
+                if (COUNT) n_imp++;
+                if (ib[j] >= 128u) return true;   // i/255 >= 0.5  <=>  i >= 128
+            }
+        }
     }
     return false;
 }
@@ -267,12 +282,27 @@ __device__ __forceinline__ bool ahead_cone(const Grid& g, const FrameParams& fp,
         const float yo = fp.cone_sin[c] * 0.2f;
         const V3 sd = normalize_exact((dir + right * xo) + new_up * yo);
         V3 pos = cur;
-        for (int i = 0; i < n; ++i) {
-            pos = pos + sd * step;
-            if (outside01(pos)) break;
-            const uint32_t ib = g.imp[nearest_offset(g, pos)];
-            if (COUNT) n_imp++;
-            if (ib >= 128u) return true;
+        bool left = false;                       // this direction has left [0,1]^3 (wgsl:122-124 break)
+        for (int i = 0; i < n && !left; i += VOLYM_PROBE_BATCH) {
+            uint32_t ib[VOLYM_PROBE_BATCH];
+            bool out[VOLYM_PROBE_BATCH];
+#pragma unroll
+            for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
+                pos = pos + sd * step;
+                out[j] = outside01(pos);
+                ib[j] = (i + j < n && !out[j]) ? g.imp[nearest_offset(g, pos)] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
+                if (!left && i + j < n) {
+                    if (out[j]) {
+                        left = true;
+                    } else {
+                        if (COUNT) n_imp++;
+                        if (ib[j] >= 128u) return true;
+                    }
+                }
+            }
         }
     }
     return false;
