@@ -152,7 +152,11 @@ def main():
     ctx.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
     ctx.set_importances(importances, dims)
     ctx.set_transfer_function(lut)
-    stream = torch.cuda.current_stream(dev)
+    # an explicit (non-null) stream shared by the march kernels, the assemble kernel and torch: RCCL's stream
+    # orders itself against THIS stream (the null stream would mean "the context's own stream" to the C ABI)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
     ctx.update(state.camera_uniforms(), state.parameter_uniforms())
 
@@ -209,6 +213,28 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # ---- untimed self-check of the N > 1 path: the gathered + assembled frame must equal the frame one context
+    # renders alone (same pixels whatever the sharding) -------------------------------------
+    gather_check = None
+    if world > 1:
+        one_frame(0)
+        drain()
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            assembled = frame.clone()
+            solo = demo.GpuContext(W, H, local_rank)
+            solo.set_option(_lib.OPT_KERNEL, args.kernel)
+            solo.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
+            solo.set_importances(importances, dims)
+            solo.set_transfer_function(lut)
+            solo.update(state.camera_uniforms(), state.parameter_uniforms())
+            solo.compute_pass()
+            solo.sync()
+            ref = torch.from_numpy(solo.read_rgba8().reshape(-1))
+            solo.close()
+            gather_check = "ok" if bool(torch.equal(assembled.cpu(), ref)) else "MISMATCH"
+        dist.barrier()
+
     # ---- roofline of the dominant kernel: HIP events on the kernel's stream, algorithmic bytes from the
     # instrumented launch (reference fetch counts) -------------------------------------------------------
     n_ev = min(max(args.steps, 10), 200)
@@ -259,6 +285,7 @@ def main():
                                {0: "direct", 1: "macro-cell", 2: "persistent+LDS-staged+queue"}[args.kernel], 1 if args.kernel == 0 else 2),
                 "viewport": [W, H], "volume": list(dims), "tile_sharding": "interleaved 16x16 tiles, k %% %d" % world,
             },
+            "gather_check": gather_check,
             "achieved_gbs": frame_bytes * args.steps / dt / 1e9,
             "b_alg_bytes_per_frame": frame_bytes,
             "b_alg_bytes_per_ray": frame_bytes / rays,

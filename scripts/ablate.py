@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--cull", type=int, nargs="*", default=[1])
     ap.add_argument("--noshade", type=int, default=0)
     ap.add_argument("--feedback", type=int, nargs="*", default=[1])
-    ap.add_argument("--dp", type=int, nargs="*", default=[64])
+    ap.add_argument("--dp", type=int, nargs="*", default=[-1])
     args = ap.parse_args()
     W, H = args.width, args.height
     dims = (256, 256, 256)
