@@ -45,7 +45,7 @@ def build_scene(args):
     importances = scene.prepare_volume(scene.map_segments_to_importance(labels, segments), dims, True)
     params = scene.StateParameters.benchmark().replace(
         raymarching_step_size=args.step, use_importance_rendering=1 if args.importance else 0,
-        use_cone_importance_check=1 if args.cone else 0)
+        use_cone_importance_check=1 if args.cone else 0, use_gaussian_smoothing=1 if args.gaussian else 0)
     state = scene.State.with_parameters(args.width / args.height, params)
     state.update()   # the frame loop's orbit(0,0,0): eye -> (0.5,0.5,1.5)  (src/event_loop.rs:100)
     return dims, volume, importances, scene.default_lut(), state
@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
     ap.add_argument("--linear", action="store_true", help="trilinear volume filter (north_star mode)")
     ap.add_argument("--importance", action="store_true")
+    ap.add_argument("--gaussian", action="store_true", help="use_gaussian_smoothing = 1 (the interactive default, src/state.rs:50)")
     ap.add_argument("--cone", action="store_true")
     ap.add_argument("--xcd-bands", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -254,7 +255,7 @@ def main():
     # HBM-side traffic of one launch: PMC counters cannot be read from inside this process; use the committed
     # rocprofv3 measurement of this exact workload when there is one (profiles/rNN_traffic.json)
     traffic, traffic_src = None, None
-    if world == 1 and args.kernel == 2 and not (args.linear or args.importance or args.cone) and (W, H, args.volume, args.step) == (1920, 1080, 256, 0.01):
+    if world == 1 and args.kernel == 2 and not (args.linear or args.importance or args.cone or args.gaussian) and (W, H, args.volume, args.step) == (1920, 1080, 256, 0.01):
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
             try:
@@ -281,7 +282,7 @@ def main():
             "config": {
                 "workload": ("teapot 256x256x178->256^3" if args.teapot else "bonsai %d^3" % args.volume) + " uint8 @ %dx%d, %s filter, step %g, thr 0.15, opacity on%s, kernel=%s (BASELINE configs[%d])"
                             % (W, H, "linear" if args.linear else "nearest (reference parity)", args.step,
-                               ", importance look-ahead %s" % ("cone" if args.cone else "straight") if args.importance else "",
+                               (", importance look-ahead %s" % ("cone" if args.cone else "straight") if args.importance else "") + (", gaussian smoothing" if args.gaussian else ""),
                                {0: "direct", 1: "macro-cell", 2: "persistent+LDS-staged+queue"}[args.kernel], 1 if args.kernel == 0 else 2),
                 "viewport": [W, H], "volume": list(dims), "tile_sharding": "interleaved 16x16 tiles, k %% %d" % world,
             },

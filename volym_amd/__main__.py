@@ -114,6 +114,34 @@ def run_simple(args):
     return 0
 
 
+def turntable(args):
+    """Scripted fly-through: the camera orbits the volume the way a mouse drag does
+    (State.process_mouse -> CameraController -> Camera::orbit, src/camera.rs:47-61, :96-117), one update +
+    compute pass per frame.  Every frame has a new view, so the kernel's cost feedback never engages: this is
+    the moving-camera figure."""
+    W, H = args.width, args.height
+    raw, labels, segments, what = _load_assets(args)
+    p = scene.StateParameters.benchmark().replace(raymarching_step_size=args.step)
+    state = scene.State.with_parameters(W / H, p)
+    state.update()
+    times = []
+    with demo.GpuContext(W, H, args.device) as ctx:
+        d = demo.Simple.init(ctx, state, volume_raw=raw, labels_raw=labels, segments=segments, dims=(256, 256, 256))
+        dx = -360.0 / args.frames / 0.2                     # mouse pixels per frame: sensitivity 0.2 deg/px, sign flipped
+        dy = -20.0 / args.frames / 0.2
+        for i in range(args.frames):
+            state.process_mouse(dx, dy if i < args.frames // 2 else -dy)
+            state.update()
+            d.update_gpu_state(ctx, state)
+            times.append(float(ctx.time_passes(1)[0]))
+            if args.out and i % max(1, args.frames // args.keep) == 0:
+                image.write_png("%s/turntable_%03d.png" % (args.out, i), ctx.read_rgba8())
+    t = np.array(times[1:] if len(times) > 1 else times)
+    print("turntable: %s, %dx%d, %d frames (one full turn): mean %.3f ms/frame, median %.3f, max %.3f => %.0f Mrays/s" % (
+        what, W, H, args.frames, t.mean(), np.median(t), t.max(), W * H / (t.mean() * 1e-3) / 1e6))
+    return 0
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="volym", description="MI355X ray-march path of volym")
     ap.add_argument("-d", "--debug", action="store_true", help="verbose logging (src/cli.rs:9-11)")
@@ -128,9 +156,15 @@ def main(argv=None):
     b.add_argument("--width", type=int, default=1024); b.add_argument("--height", type=int, default=768)   # src/main.rs:356-359
     b.add_argument("--secs", type=float, default=0.25, help="GPU seconds per trial (the reference uses 2 s of wall clock)")
     b.add_argument("--output", default="benchmark_results.csv")
+    tt = sub.add_parser("turntable", help="scripted orbit of the camera (moving-view timing)")
+    tt.add_argument("--width", type=int, default=1920); tt.add_argument("--height", type=int, default=1080)
+    tt.add_argument("--frames", type=int, default=72); tt.add_argument("--step", type=float, default=0.01)
+    tt.add_argument("--out"); tt.add_argument("--keep", type=int, default=6)
     args = ap.parse_args(argv)
     if args.command == "benchmark":
         return benchmark(args)
+    if args.command == "turntable":
+        return turntable(args)
     if args.command is None:
         args.width, args.height, args.screenshot = 1280, 720, None
     return run_simple(args)

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     uint32_t* __restrict__ out_shard, uint32_t* __restrict__ out_raster, float4* __restrict__ out_f32,
     Counters* __restrict__ counters, uint4* __restrict__ trace, const FrameParams fp)
 {
-    constexpr int K = TABLE ? KSPEC : 1;     // speculation depth
+    constexpr int K = TABLE ? KSPEC : 2;     // speculation depth (continuous-rho modes: 2 -- each sample is 5-8 gathers)
     unsigned long long trace_t0 = 0;
     uint32_t trace_iters = 0, trace_flushes = 0, trace_tiles = 0, trace_marched = 0;
     unsigned long long tm_leap = 0, tm_samp = 0, tm_flush = 0, tm_setup = 0, tm_mark = 0, tm_addr = 0, tm_wait = 0;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     __shared__ float4 s_lut[TABLE ? 1 : 256];
     __shared__ float s_ic_alpha[256];
     __shared__ float s_rho[256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_df[TABLE ? VOLYM_DF_LDS_BYTES : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_df[VOLYM_DF_LDS_BYTES];
     __shared__ float s_qx[PQ_WAVES][PQ_QCAP], s_qy[PQ_WAVES][PQ_QCAP], s_qz[PQ_WAVES][PQ_QCAP], s_qw[PQ_WAVES][PQ_QCAP];
     __shared__ uint32_t s_qm[PQ_WAVES][PQ_QCAP];
     __shared__ float s_qr[TABLE ? 1 : PQ_WAVES][TABLE ? 1 : PQ_QCAP];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             s_ic_alpha[i] = tables->ic_alpha[i];
             if (!TABLE) s_lut[i] = tables->lut_f[i];
         }
-        if (TABLE) {
+        {
             const uint32_t n16 = (fp.mc_n * fp.mc_n * fp.mc_n / 2u + 15u) / 16u;
             const uint4* src = reinterpret_cast<const uint4*>(df4);
             uint4* dst = reinterpret_cast<uint4*>(s_df);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             // raymarch_kernels.h VARIANT 1).  Cells with distance value < PQ_MIN_LEAP_D are simply sampled:
             // a one-cell leap replays ~3 steps, which the K-wide speculation below covers in the same
             // iteration without the ~100 instructions and the LDS round trip of a leap. ----
-            if (TABLE && active) {
+            if (active) {
                 if (!(t < t_end && acc_a < 0.95f)) {              // wgsl:250 (t_end: nothing dense beyond)
                     active = false;
                 } else if (!last_dense) {
@@ -333,7 +333,8 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         D = (static_cast<uint32_t>(s_df[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
                     }
                     if (D >= PQ_MIN_LEAP_D) {
-                        const float eps = 4.0e-5f;
+                        // smoothing taps sit up to 2*0.005 along the ray from the sample (wgsl:53-60): keep them inside too
+                        const float eps = gauss ? 4.0e-5f + 0.0101f : 4.0e-5f;
                         const float a = static_cast<float>(D - 1u) * inv_mc - eps;
                         const float lx = __builtin_fmaf(cxf, inv_mc, -a), hx = __builtin_fmaf(cxf, inv_mc, a + inv_mc);
                         const float ly = __builtin_fmaf(cyf, inv_mc, -a), hy = __builtin_fmaf(cyf, inv_mc, a + inv_mc);
@@ -346,7 +347,15 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         // D >= 2: the cell of pos lies at least one whole cell inside the box, no `inside` test needed
                         const float t_stop = __builtin_fminf(te, t_end);
                         while (t < t_stop) {                          // replay of empty steps, wgsl:263-274
-                            if (COUNT) { n_steps++; n_vol++; n_imp++; }
+                            if (COUNT) {
+                                n_steps++; n_imp++;
+                                if (gauss) {                          // the shader fetches the taps that lie inside [0,1]^3 (wgsl:58-66)
+                                    const V3 q = ray.o + ray.d * t;
+                                    for (int i = -2; i <= 2; ++i) if (!outside01(q + ray.d * (static_cast<float>(i) * 0.005f))) n_vol++;
+                                } else {
+                                    n_vol++;
+                                }
+                            }
                             cur = __builtin_fminf(base, cur * 1.5f);
                             t += cur;
                         }
@@ -450,6 +459,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             float ts[K];
             uint32_t offs[K], bs[K], ibs[K];
             float rhos[K];
+            uint32_t taps[K];                                       // reference fetches of sample k (instrumented launch)
             {
                 float tt = t, cc = cur;
 #pragma unroll
@@ -464,10 +474,17 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 if (TRACE) { ta = PQ_TICK(); tm_addr += ta - tm_mark; }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    bs[k] = 0; ibs[k] = 0; rhos[k] = 0.0f;
+                    bs[k] = 0; ibs[k] = 0; rhos[k] = 0.0f; taps[k] = 1;
                     if (active) {
                         if (TABLE) bs[k] = vol[offs[k]];
                         if (need_imp) ibs[k] = imp[offs[k]];
+                        if (!TABLE) {                                   // wgsl:253-259, all K densities in flight together
+                            const V3 p = ray.o + ray.d * ts[k];
+                            uint32_t cnt = 0;
+                            if (gauss) rhos[k] = sample_density_smoothed<true>(g, s_rho, linear, fp, p, ray.d, cnt);
+                            else { rhos[k] = sample_density(g, s_rho, linear, p); cnt = 1; }
+                            taps[k] = cnt;
+                        }
                     }
                 }
                 if (TRACE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tm_wait += PQ_TICK() - ta; }
@@ -489,8 +506,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         if (COUNT) n_vol++;
                         dense = bs[k] >= fp.thr_byte;             // <=> b/255 >= thr
                     } else {
-                        if (gauss) rhos[k] = sample_density_smoothed<COUNT>(g, s_rho, linear, fp, pos, ray.d, n_vol);
-                        else { rhos[k] = sample_density(g, s_rho, linear, pos); if (COUNT) n_vol++; }
+                        if (COUNT) n_vol += taps[k];
                         dense = rhos[k] >= thr;
                     }
                     const bool predicted = last_dense;
