@@ -29,7 +29,6 @@ def main():
     ap.add_argument("--wgs", type=int, nargs="*", default=[2])
     ap.add_argument("--kspec", type=int, nargs="*", default=[4])
     ap.add_argument("--cull", type=int, nargs="*", default=[1])
-    ap.add_argument("--noshade", type=int, default=0)
     ap.add_argument("--feedback", type=int, nargs="*", default=[1])
     ap.add_argument("--dp", type=int, nargs="*", default=[-1])
     ap.add_argument("--fine", type=int, nargs="*", default=[64])
@@ -62,8 +61,6 @@ def main():
                     ctx.set_option(102, ks)
                     ctx.set_option(103, cl)
                     ctx.set_option(104, fb)
-                    if k == 2:
-                        ctx.set_option(_lib.OPT_XCD_BANDS, 0x100 if args.noshade else 0)
                     ctx.set_option(_lib.OPT_KERNEL, k)
                     ctx.set_option(_lib.OPT_XCD_BANDS if k != 2 else 101, b)
                     ctx.update(cu, pu)

@@ -69,6 +69,7 @@ struct volym_ctx {
     uint32_t frames_since_change = 0;
     bool order_by_cost = false;    // d_order currently reflects measured cost
     bool feedback = true;
+    bool super_fill = true;
     int dp_min_cost = -1;          // measured tile cost from which a tile is marched depth-parallel (0 = never, < 0 = adaptive)
     uint32_t n_items = 0;
     bool order_dirty = true;
@@ -224,8 +225,12 @@ int volym_set_option(volym_ctx* c, int key, int value)
         c->kspec = value;
         return VOLYM_OK;
     case 105:   // undocumented: measured cost from which tiles are marched depth-parallel (0 = never)
-        if (value < -1 || value > 65535) return fail(c, VOLYM_E_INVALID, "dp cost threshold: -1 (adaptive), 0 (off) .. 65535");
+        if (value < -100 || value > 65535) return fail(c, VOLYM_E_INVALID, "dp cost threshold: < 0 adaptive (-N = N/10 x fair share), 0 off, else explicit");
         c->dp_min_cost = value;
+        c->order_dirty = true;
+        return VOLYM_OK;
+    case 107:   // undocumented: 0 disables the 16x16 super fill items (A/B tests)
+        c->super_fill = value != 0;
         c->order_dirty = true;
         return VOLYM_OK;
     case 104:   // undocumented: 0 disables the cost-feedback reordering of variant 2 (A/B tests)
@@ -237,7 +242,7 @@ int volym_set_option(volym_ctx* c, int key, int value)
         c->hull_dirty = true;
         return VOLYM_OK;
     case 100:   // undocumented tuning knob: block->tile remap bands per XCD (0 = identity)
-        if (value < 0 || value > 0x1ff) return fail(c, VOLYM_E_INVALID, "xcd bands: 0..64 (+0x100 dev bit)");
+        if (value < 0 || value > 64) return fail(c, VOLYM_E_INVALID, "xcd bands: 0..64");
         c->xcd_bands = static_cast<uint32_t>(value);
         return VOLYM_OK;
     default:
@@ -420,13 +425,27 @@ static int reorder_by_cost(volym_ctx* c)
     uint64_t total_cost = 0;
     for (uint32_t item : c->h_order) total_cost += cost[item];
     const uint32_t resident_waves = static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu * PQ_WAVES;
-    const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(64, 2 * total_cost / std::max(1u, resident_waves) + 16));
+    // dp_min_cost < 0 encodes the factor in tenths (-20 = 2.0 x fair share, the default -1 means 2.0)
+    const uint64_t tenths = c->dp_min_cost < -1 ? static_cast<uint64_t>(-c->dp_min_cost) : 20u;
+    const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(64, tenths * total_cost / (10u * std::max(1u, resident_waves)) + 16));
     const uint32_t dp_thr = c->dp_min_cost < 0 ? adaptive : static_cast<uint32_t>(c->dp_min_cost);
     const bool dp_ok = c->dp_min_cost != 0 && !(c->fp.flags & (F_LINEAR | F_GAUSSIAN | F_IMP_RENDERING));
     std::vector<std::pair<uint32_t, uint32_t>> keyed;      // (cost share, item)
     keyed.reserve(c->h_order.size() * 2);
+    // 16x16 tiles whose four sub-tiles were all constant become one "super" fill item (bit 30)
+    std::vector<uint8_t> all_fill(c->n_local, 1), seen(c->n_local, 0);
+    for (uint32_t item : c->h_order) if (cost[item] != 0) all_fill[item >> 2] = 0;
+    {
+        std::vector<uint8_t> cnt(c->n_local, 0);
+        for (uint32_t item : c->h_order) cnt[item >> 2]++;
+        for (uint32_t lt = 0; lt < c->n_local; ++lt) if (cnt[lt] != 4) all_fill[lt] = 0;   // sub-tiles outside the frame are not listed
+    }
     for (uint32_t item : c->h_order) {
         const uint32_t k = cost[item];
+        if (c->super_fill && all_fill[item >> 2]) {
+            if (!seen[item >> 2]) { seen[item >> 2] = 1; keyed.emplace_back(0u, 0x40000000u | (item >> 2)); }
+            continue;
+        }
         if (dp_ok && k >= dp_thr)
             for (uint32_t qd = 0; qd < 4; ++qd) keyed.emplace_back((k + 3u) / 4u, 0x80000000u | (item << 2) | qd);
         else

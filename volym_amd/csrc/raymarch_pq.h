@@ -45,6 +45,7 @@ namespace volym {
 constexpr int PQ_WAVES = 16;             // waves per workgroup
 constexpr int PQ_THREADS = PQ_WAVES * 64;
 constexpr uint32_t PQ_MIN_LEAP_D = 2;    // smallest distance-field value worth a leap
+constexpr int PQ_ITEMS_LDS = 512;       // work-list entries staged in LDS per workgroup (the rest stay in global memory)
 constexpr int PQ_QCAP = 128;             // ring entries per wave (>= 64 queued + 64 new)
 constexpr float PQ_FIX_SCALE = 268435456.0f;        // 2^28
 constexpr float PQ_FIX_INV = 1.0f / 268435456.0f;
@@ -56,12 +57,12 @@ __device__ __forceinline__ uint32_t lane_rank_in_mask(unsigned long long mask)
 
 enum : uint32_t { TILE_MARCH = 0, TILE_HIT_TEST = 1, TILE_FILL_EMPTY = 2, TILE_FILL_MISS = 3 };
 
-// Classify the pixel rectangle [x0, x0+7] x [y0, y0+7] against the two projected hulls (wave-uniform
+// Classify the pixel rectangle [x0, x0+extent] x [y0, y0+extent] against the two projected hulls (wave-uniform
 // result; lane l evaluates hull l>>5, edge (l>>2)&7, corner l&3).
-__device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, uint32_t lane, float x0, float y0)
+__device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, uint32_t lane, float x0, float y0, float extent = 7.0f)
 {
     const uint32_t h = lane >> 5, e = (lane >> 2) & 7u, k = lane & 3u;
-    const float cx = (k & 1u) ? x0 + 7.0f : x0, cy = (k & 2u) ? y0 + 7.0f : y0;
+    const float cx = (k & 1u) ? x0 + extent : x0, cy = (k & 2u) ? y0 + extent : y0;
     const float a = fp.hull[h][e][0], b = fp.hull[h][e][1], c = fp.hull[h][e][2];
     const bool valid = fp.hull[h][e][3] > 0.5f;
     const float v = __builtin_fmaf(a, cx, __builtin_fmaf(b, cy, c));
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     __shared__ float s_qr[TABLE ? 1 : PQ_WAVES][TABLE ? 1 : PQ_QCAP];
     __shared__ uint32_t s_acc[PQ_WAVES][3][64];
     __shared__ uint32_t s_next_ticket;
+    __shared__ uint32_t s_items[PQ_ITEMS_LDS];          // this workgroup's work list (items b, b+G, ...)
 
     const uint32_t flags = fp.flags;
     const bool linear = (flags & F_LINEAR) != 0u;
@@ -112,6 +114,10 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     {
         const uint32_t i = threadIdx.x;
         if (i == 0u) s_next_ticket = 0u;
+        if (i < PQ_ITEMS_LDS) {
+            const size_t gi = blockIdx.x + static_cast<size_t>(gridDim.x) * i;
+            if (gi < n_items) s_items[i] = order[gi];
+        }
         if (i < 256u) {
             s_tf_tab[i] = tables->tf_tab[i];
             s_rho[i] = tables->rho[i];
@@ -161,7 +167,42 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         // item = local_tile*4 + sub (an 8x8 wave tile, one lane per ray), or, for tiles the cost feedback
         // found expensive, bit 31 | (that id << 2) | quarter: a 4x4 quarter tile marched DEPTH-PARALLEL,
         // four lanes per ray, lane k of a quad taking the k-th speculative sample (see "dp" below)
-        const uint32_t raw = __builtin_amdgcn_readfirstlane(order[blockIdx.x + static_cast<size_t>(gridDim.x) * ticket]);
+        const uint32_t raw0 = __builtin_amdgcn_readfirstlane(ticket < PQ_ITEMS_LDS ? s_items[ticket] : order[blockIdx.x + static_cast<size_t>(gridDim.x) * ticket]);
+        // bit 30 (bit 31 clear): a whole 16x16 tile that was constant in the frame the costs were measured on.  One
+        // classification of the 16x16 rectangle and, if it still says "constant", 16-byte stores; otherwise its four
+        // sub-tiles are processed here one after the other.
+        const bool is_super = (raw0 >> 30) == 1u;
+        uint32_t n_sub = 1;
+        if (is_super) {
+            const uint32_t lt = raw0 & 0x3fffffffu;
+            const uint32_t tile16 = lt * fp.world + fp.rank;
+            const uint32_t tx16 = tile16 % fp.tiles_x, ty16 = tile16 / fp.tiles_x;
+            const uint32_t cls = culling ? classify_tile(fp, lane, static_cast<float>(tx16 * 16u), static_cast<float>(ty16 * 16u), 15.0f) : TILE_MARCH;
+            if (cls >= TILE_FILL_EMPTY) {
+                const uint32_t packed = cls == TILE_FILL_MISS ? 0xff000000u : 0u;
+                if (flags & F_RASTER) {
+                    const uint32_t gx4 = tx16 * 16u + (lane & 3u) * 4u, gy4 = ty16 * 16u + (lane >> 2);
+                    if (gy4 < fp.H) {
+                        for (uint32_t i = 0; i < 4u; ++i)
+                            if (gx4 + i < fp.W) {
+                                out_raster[static_cast<size_t>(gy4) * fp.W + gx4 + i] = packed;
+                                if (flags & F_WRITE_F32) out_f32[static_cast<size_t>(gy4) * fp.W + gx4 + i] = make_float4(0.0f, 0.0f, 0.0f, cls == TILE_FILL_MISS ? 1.0f : 0.0f);
+                            }
+                    }
+                } else {
+                    // shard layout: sub-tile major, 64 pixels each; pixels outside the frame are zero
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        const uint32_t sl = lane * 4u + i, sub4 = sl >> 6, in = sl & 63u;
+                        const uint32_t gxx = tx16 * 16u + ((sub4 & 1u) << 3) + (in & 7u), gyy = ty16 * 16u + ((sub4 >> 1) << 3) + (in >> 3);
+                        out_shard[static_cast<size_t>(lt) * 256u + sl] = (gxx < fp.W && gyy < fp.H) ? packed : 0u;
+                    }
+                }
+                continue;
+            }
+            n_sub = 4;
+        }
+      for (uint32_t sub_iter = 0; sub_iter < n_sub; ++sub_iter) {
+        const uint32_t raw = is_super ? ((raw0 & 0x3fffffffu) * 4u + sub_iter) : raw0;
         const bool is_quarter = (raw >> 31) != 0u;
         const bool dp = is_quarter && TABLE && !COUNT;
         const uint32_t item = is_quarter ? ((raw & 0x7fffffffu) >> 2) : raw;
@@ -248,7 +289,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             if (TRACE) { trace_flushes++; fl0 = PQ_TICK(); }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lane < n && !(fp.xcd_bands & 0x100u)) {   // bit 8 of the dev knob: skip shading (timing experiment only)
+            if (lane < n) {
                 const uint32_t e = (q_head + lane) & (PQ_QCAP - 1);
                 const V3 pos = v3(qx[e], qy[e], qz[e]);
                 const float w = qw[e];
@@ -573,6 +614,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         if (cost && !dp && lane == 0) cost[item] = static_cast<uint16_t>(min(65535u, 1u + tile_iters * 8u + tile_flushes * 3u));
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
+      }
       }
     }
 
