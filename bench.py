@@ -238,10 +238,9 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events on the kernel's stream, algorithmic bytes from the
     # instrumented launch (reference fetch counts) -------------------------------------------------------
-    n_ev = min(max(args.steps, 10), 200)
-    ms = ctx.time_passes(n_ev)
+    n_ev = min(max(args.steps, 10), 500)
+    kernel_ms = ctx.time_batch(n_ev) / n_ev      # HIP events on the kernel's stream, one pair around n_ev launches
     ctx.sync()
-    kernel_ms = float(np.mean(ms))
     st = ctx.stats_pass()
     counts = torch.tensor([st["n_vol"], st["n_imp"], st["n_rays"]], dtype=torch.int64, device=dev)
     if world > 1:

@@ -161,6 +161,8 @@ int volym_stats_pass(volym_ctx* ctx, volym_stats* out);
 /* n back-to-back compute passes timed with HIP events on the context's stream;
  * ms_each[n] receives each pass's duration (kernel only, inputs resident). */
 int volym_time_passes(volym_ctx* ctx, uint32_t n, float* ms_each);
+/* the same with ONE event pair around all n passes (no event packets between the kernels): total milliseconds */
+int volym_time_batch(volym_ctx* ctx, uint32_t n, float* ms_total);
 
 #ifdef __cplusplus
 }

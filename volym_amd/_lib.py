@@ -139,6 +139,7 @@ SIGNATURES = {
     "volym_assemble_host": (C.c_int, [_ctx, _u8p]),
     "volym_stats_pass": (C.c_int, [_ctx, C.POINTER(Stats)]),
     "volym_time_passes": (C.c_int, [_ctx, C.c_uint32, _f32p]),
+    "volym_time_batch": (C.c_int, [_ctx, C.c_uint32, _f32p]),
     # include/volym_host.h
     "volym_camera_default_with_aspect_and_pos": (None, [C.POINTER(CCamera), C.c_float, _f32p]),
     "volym_camera_orbit": (None, [C.POINTER(CCamera), C.c_float, C.c_float, C.c_float]),

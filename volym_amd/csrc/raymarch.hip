@@ -886,6 +886,25 @@ int volym_dev_wave_trace(volym_ctx* c, uint32_t* out, uint32_t max_records)
     return rc == VOLYM_OK ? static_cast<int>(records) : rc;
 }
 
+int volym_time_batch(volym_ctx* c, uint32_t n, float* ms_total)
+{
+    if (!c || !ms_total || n == 0 || n > 1000000) return VOLYM_E_INVALID;
+    if (!c->have_frame) return fail(c, VOLYM_E_STATE, "volym_time_batch: call volym_update first");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return fail(c, VOLYM_E_HIP, "hipEventCreate failed"); }
+    int rc = ensure_frame_resources(c);
+    if (rc == VOLYM_OK) {
+        (void)hipEventRecord(e0, c->stream);
+        for (uint32_t i = 0; i < n && rc == VOLYM_OK; ++i) rc = launch_march<false>(c);
+        (void)hipEventRecord(e1, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess && rc == VOLYM_OK) rc = fail(c, VOLYM_E_HIP, "hipStreamSynchronize failed");
+        if (rc == VOLYM_OK && hipEventElapsedTime(ms_total, e0, e1) != hipSuccess) rc = fail(c, VOLYM_E_HIP, "hipEventElapsedTime failed");
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
 int volym_time_passes(volym_ctx* c, uint32_t n, float* ms_each)
 {
     if (!c || !ms_each || n == 0 || n > 100000) return VOLYM_E_INVALID;

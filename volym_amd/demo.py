@@ -134,6 +134,12 @@ class GpuContext:
         self._ck(_lib.lib().volym_stats_pass(self.handle, C.byref(s)))
         return s.as_dict()
 
+    def time_batch(self, n):
+        """n back-to-back passes between one pair of HIP events: total milliseconds."""
+        ms = C.c_float(0.0)
+        self._ck(_lib.lib().volym_time_batch(self.handle, int(n), C.byref(ms)))
+        return float(ms.value)
+
     def time_passes(self, n):
         ms = np.zeros(int(n), np.float32)
         self._ck(_lib.lib().volym_time_passes(self.handle, int(n), scene._f32p(ms)))
