@@ -67,10 +67,14 @@ def cpu_baseline(args, dims, volume, importances, lut, state, budget_s=12.0):
     per_row = (time.perf_counter() - t0) / 8.0
     rows_budget = max(8, int(budget_s / max(per_row, 1e-6)))
     if rows_budget >= H:
-        t0 = time.perf_counter()
-        _, _, k = O.render(volume, importances, dims, lut, cam, par, W, H, filter=filt, threads=cores, want_f32=False)
-        dt = time.perf_counter() - t0
-        rays, sample = W * H, "full %dx%d frame, 1 pass" % (W, H)
+        passes = int(min(max(budget_s / max(per_row * H, 1e-6), 1), 20))     # whole frames until the budget is used
+        times = []
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            _, _, k = O.render(volume, importances, dims, lut, cam, par, W, H, filter=filt, threads=cores, want_f32=False)
+            times.append(time.perf_counter() - t0)
+        dt = sorted(times)[len(times) // 2]
+        rays, sample = W * H, "full %dx%d frame, median of %d passes" % (W, H, passes)
     else:
         stride = (H + rows_budget - 1) // rows_budget
         rows = list(range(0, H, stride))
