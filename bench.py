@@ -10,8 +10,9 @@ with step 0.01, the reference's effective camera eye (0.5,0.5,1.5)).  The real .
 the repository (.MISSING_LARGE_BLOBS), so the volume is volym_amd.synth.synth_bonsai(256).
 
 N > 1: the framebuffer is sharded by interleaved 16x16 screen tiles over the ranks, the volume
-is replicated, and every frame's shards are gathered to every rank over RCCL (all_gather) and
-assembled into a raster on rank 0; frame i's gather overlaps frame i+1's march (two buffers).
+is replicated, and every frame's shards are gathered to rank 0 over RCCL (rooted gather: direct
+sends over separate xGMI links) and assembled into a raster there; a frame's gather overlaps the
+marches of the next three frames (four buffers).
 Total work per step is fixed, so scaling is "strong".
 """
 import argparse
@@ -166,10 +167,13 @@ def main():
     ctx.update(state.camera_uniforms(), state.parameter_uniforms())
 
     shard_bytes = ctx.shard_bytes()
-    nbuf = 2
+    nbuf = 4       # frames in flight: frame i's gather overlaps the marches of frames i+1..i+3
     if world > 1:
         shards = [torch.empty(shard_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-        gathered = [torch.empty(shard_bytes * world, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        # only the root consumes the frame: a rooted gather = direct sends to rank 0 over separate xGMI links
+        # (a ring all_gather would move 7x the bytes through every link; the message is 1 MB per rank at 1080p)
+        gathered = [torch.empty(shard_bytes * world, dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(nbuf)]
+        gather_lists = [list(g.view(world, shard_bytes).unbind(0)) if g is not None else None for g in gathered]
     frame = torch.empty(W * H * 4, dtype=torch.uint8, device=dev)
     ctx.bind_output(shards[0].data_ptr() if world > 1 else None, frame.data_ptr())
 
@@ -187,7 +191,7 @@ def main():
             pending[b] = None
         ctx.bind_output(shards[b].data_ptr(), frame.data_ptr())
         ctx.compute_pass()
-        pending[b] = dist.all_gather_into_tensor(gathered[b], shards[b], async_op=True)
+        pending[b] = dist.gather(shards[b], gather_lists[b], dst=0, async_op=True)
 
     def drain():
         for b in range(nbuf):

@@ -1,5 +1,5 @@
 """The N > 1 protocol of bench.py on CPU: world_size-2 (and 3) gloo process groups shard the frame by
-interleaved 16x16 tiles, all_gather the shards and assemble the raster on every rank.  The renderer
+interleaved 16x16 tiles, gather the shards to rank 0 and assemble the raster there.  The renderer
 here is the oracle (there is no GPU in this tier); the shard layout is volym_amd/sharding.py, which
 the GPU tests check against the HIP kernels (tests/test_gpu_parity.py)."""
 import os
@@ -31,10 +31,15 @@ def _worker(rank, world, port, W, H, out_dir):
     _, full, _ = O.render(vol, imp, dims, O.tf_default_lut(), cam, par, W, H, threads=1)
     mine = torch.from_numpy(sharding.pack_shard(full, rank, world).copy())
     assert mine.numel() == sharding.shard_bytes(W, H, world)
-    gathered = torch.empty(mine.numel() * world, dtype=torch.uint8)
-    dist.all_gather_into_tensor(gathered, mine)
-    frame = sharding.assemble(gathered.numpy(), W, H, world)
-    ok = bool(np.array_equal(frame, full))
+    # bench.py's exchange: a rooted gather to rank 0, which assembles the raster
+    gathered = torch.empty(mine.numel() * world, dtype=torch.uint8) if rank == 0 else None
+    parts = list(gathered.view(world, mine.numel()).unbind(0)) if rank == 0 else None
+    work = dist.gather(mine, parts, dst=0, async_op=True)
+    work.wait()
+    ok = True
+    if rank == 0:
+        frame = sharding.assemble(gathered.numpy(), W, H, world)
+        ok = bool(np.array_equal(frame, full))
     t = torch.tensor([1.0 + rank])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)            # bench.py takes the max over ranks of the step time
     assert float(t) == float(world)
