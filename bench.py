@@ -300,7 +300,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "volym_raymarch_pq_kernel<true,false,false,4>" if args.kernel == 2 else "volym_raymarch_kernel<%d,false,false>" % args.kernel,
+                "kernel": "volym_raymarch_pq_kernel<true,false,false,4,false>" if args.kernel == 2 else "volym_raymarch_kernel<%d,false,false>" % args.kernel,
                 "kernel_avg_ms": kernel_ms, "launch_algorithmic_bytes": local_bytes,
                 "note": "algorithmic bytes = reference fetch count (n_vol*%d + n_imp) + 4 B/pixel; the 32 MiB working set is "
                         "Infinity-Cache resident, so HBM traffic << algorithmic bytes (DESIGN.md)" % b_vol,

@@ -714,7 +714,11 @@ static int launch_march(volym_ctx* c)
 #define VOLYM_PQ_LAUNCH(T, KS)                                                                                                   \
     hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT, TRACE, KS>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,  \
                        c->d_imp, c->d_tables, c->d_df, c->d_order, c->n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
-        if (table && c->kspec == 8) VOLYM_PQ_LAUNCH(true, 8);
+        const bool no_imp = !(fp.flags & (F_IMP_COLORING | F_IMP_RENDERING | F_WRITE_F32)) && (fp.flags & F_OPACITY) && (fp.flags & F_RASTER);
+        if (table && c->kspec == 4 && no_imp && !COUNT && !TRACE)
+            hipLaunchKernelGGL((volym_raymarch_pq_kernel<true, false, false, 4, false>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,
+                               c->d_imp, c->d_tables, c->d_df, c->d_order, c->n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp);
+        else if (table && c->kspec == 8) VOLYM_PQ_LAUNCH(true, 8);
         else if (table && c->kspec == 4) VOLYM_PQ_LAUNCH(true, 4);
         else if (table && c->kspec == 2) VOLYM_PQ_LAUNCH(true, 2);
         else if (table) VOLYM_PQ_LAUNCH(true, 1);

@@ -78,7 +78,7 @@ __device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, uint32_
     if (out_obj) return in_cube ? TILE_FILL_EMPTY : TILE_HIT_TEST;
     return TILE_MARCH;
 }
-template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1>
+template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true>
 __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
     const uint8_t* __restrict__ df4, const uint32_t* __restrict__ order, uint32_t n_items, uint16_t* __restrict__ cost,
@@ -104,11 +104,15 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     __shared__ uint32_t s_next_ticket;
     __shared__ uint32_t s_items[PQ_ITEMS_LDS];          // this workgroup's work list (items b, b+G, ...)
 
-    const uint32_t flags = fp.flags;
+    // IMP = false also pins the other frame-constant flags of the common case (opacity on, raster output, no float
+    // side buffer) so that their tests fold away; every other combination runs the IMP = true instantiation
+    const uint32_t flags = IMP ? fp.flags : ((fp.flags & ~(F_IMP_COLORING | F_IMP_RENDERING | F_CONE | F_WRITE_F32)) | F_OPACITY | F_RASTER);
     const bool linear = (flags & F_LINEAR) != 0u;
     const bool gauss = (flags & F_GAUSSIAN) != 0u;
-    const bool imp_coloring = (flags & F_IMP_COLORING) != 0u;
-    const bool imp_rendering = (flags & F_IMP_RENDERING) != 0u;
+    // IMP = false: instantiation for frames with both importance modes off (the reference's "Base" rows): the
+    // look-ahead and importance-colouring code, its registers and its scalar state are compiled out
+    const bool imp_coloring = IMP && (flags & F_IMP_COLORING) != 0u;
+    const bool imp_rendering = IMP && (flags & F_IMP_RENDERING) != 0u;
     const bool need_imp = imp_coloring || imp_rendering;
 
     {
