@@ -69,15 +69,12 @@ def main():
             tiles.mean(), tiles.max(), marched.mean(), marched.max(), iters.mean(), iters.max(), flushes.mean(), flushes.max()))
         print("totals: tiles %d marched %d iterations %d flushes %d" % (tiles.sum(), marched.sum(), iters.sum(), flushes.sum()))
         print("us per loop iteration (waves with >=10 iterations): %.3f" % ((dur[iters >= 10] / iters[iters >= 10]).mean() / 100))
-        addr_t = (ph[:, 3] & 0xFFFF).astype(np.float64) * 256.0
-        wait_t = (ph[:, 3] >> 16).astype(np.float64) * 256.0
+        lanes = (ph[:, 3] & 0xFFFF).astype(np.float64)
+        accepted = (ph[:, 3] >> 16).astype(np.float64)
         ph = ph.copy(); ph[:, 3] = 0
         tick = ph.astype(np.float64) * 16.0          # shader clock ticks
-        print("sample phase split, all waves: address calc %.1f%%  load wait %.1f%%  of sample-phase ticks" % (
-            100.0 * addr_t.sum() / tick[:, 1].sum(), 100.0 * wait_t.sum() / tick[:, 1].sum()))
-        sl = np.argsort(dur)[-16:]
-        print("slowest 16 waves: per iteration: address calc %.0f  load wait %.0f  (sample phase %.0f)" % (
-            addr_t[sl].sum() / iters[sl].sum(), wait_t[sl].sum() / iters[sl].sum(), tick[sl, 1].sum() / iters[sl].sum()))
+        print("lane utilisation at the loop top %.1f%% ; samples accepted per active lane-iteration %.2f ; per wave-iteration %.1f (of %d slots)" % (
+            100.0 * lanes.sum() / (64.0 * iters.sum()), accepted.sum() / lanes.sum(), accepted.sum() / iters.sum(), 256))
         tot = tick.sum(axis=0)
         print("phase shares over all waves (shader ticks): leap %.1f%%  sample %.1f%%  flush %.1f%%  setup+store %.1f%%  ; ticks per us of wave time: %.0f" % (
             *(100.0 * tot / tot.sum()), tot.sum() / (dur.sum() / 100.0)))
@@ -90,6 +87,22 @@ def main():
         # per workgroup (16 waves): end time spread
         wg_end = end[: len(end) // 16 * 16].reshape(-1, 16).max(axis=1)
         print("workgroup end us: min %.1f p50 %.1f p90 %.1f max %.1f" % (wg_end.min() / 100, np.percentile(wg_end, 50) / 100, np.percentile(wg_end, 90) / 100, wg_end.max() / 100))
+        n16 = len(end) // 16 * 16
+        wg_it = iters[:n16].reshape(-1, 16).sum(axis=1).astype(np.float64)
+        wg_fl = flushes[:n16].reshape(-1, 16).sum(axis=1).astype(np.float64)
+        wg_busy = dur[:n16].reshape(-1, 16).sum(axis=1) / 100.0
+        wg_max_wave_it = iters[:n16].reshape(-1, 16).max(axis=1)
+        print("per workgroup: iterations min %d p50 %d max %d ; flushes min %d p50 %d max %d ; busy wave-us min %.0f p50 %.0f max %.0f" % (
+            wg_it.min(), np.percentile(wg_it, 50), wg_it.max(), wg_fl.min(), np.percentile(wg_fl, 50), wg_fl.max(), wg_busy.min(), np.percentile(wg_busy, 50), wg_busy.max()))
+        print("corr(workgroup end, iterations) %.2f ; corr(end, flushes) %.2f ; corr(end, max wave iterations) %.2f ; corr(end, busy) %.2f" % (
+            np.corrcoef(wg_end, wg_it)[0, 1], np.corrcoef(wg_end, wg_fl)[0, 1], np.corrcoef(wg_end, wg_max_wave_it)[0, 1], np.corrcoef(wg_end, wg_busy)[0, 1]))
+        o = np.argsort(wg_end)
+        for tag, sel in (("earliest 8 workgroups", o[:8]), ("latest 8 workgroups", o[-8:])):
+            print(tag, "end", [round(float(x) / 100, 1) for x in wg_end[sel]], "iters", [int(x) for x in wg_it[sel]], "flushes", [int(x) for x in wg_fl[sel]], "max wave iters", [int(x) for x in wg_max_wave_it[sel]], "wg id", [int(x) for x in sel])
+        w_end = end[:n16].reshape(-1, 16)
+        print("last-wave lead inside a workgroup (end of last wave - end of 2nd last) us: mean %.1f max %.1f ; (last - median wave) mean %.1f" % (
+            np.mean(np.sort(w_end, axis=1)[:, -1] - np.sort(w_end, axis=1)[:, -2]) / 100, np.max(np.sort(w_end, axis=1)[:, -1] - np.sort(w_end, axis=1)[:, -2]) / 100,
+            np.mean(np.sort(w_end, axis=1)[:, -1] - np.median(w_end, axis=1)) / 100))
     else:
         it, dn = r[:, 2], r[:, 3]
         print("iterations/wave (max lane): mean %.1f p90 %d max %d ; dense/wave (max lane): mean %.1f max %d" % (it.mean(), np.percentile(it, 90), it.max(), dn.mean(), dn.max()))

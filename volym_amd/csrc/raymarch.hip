@@ -70,6 +70,7 @@ struct volym_ctx {
     bool order_by_cost = false;    // d_order currently reflects measured cost
     bool feedback = true;
     bool super_fill = true;
+    uint32_t prio_tenths[3] = {3, 6, 10};   // cost / fair share (tenths) from which an item runs at issue priority 1, 2, 3 (first 0: off)
     int dp_min_cost = -1;          // measured tile cost from which a tile is marched depth-parallel (0 = never, < 0 = adaptive)
     uint32_t n_items = 0;
     bool order_dirty = true;
@@ -227,6 +228,13 @@ int volym_set_option(volym_ctx* c, int key, int value)
     case 105:   // undocumented: measured cost from which tiles are marched depth-parallel (0 = never)
         if (value < -100 || value > 65535) return fail(c, VOLYM_E_INVALID, "dp cost threshold: < 0 adaptive (-N = N/10 x fair share), 0 off, else explicit");
         c->dp_min_cost = value;
+        c->order_dirty = true;
+        return VOLYM_OK;
+    case 108:   // undocumented: issue-priority thresholds t1 + 100*t2 + 10000*t3 in tenths of the fair share (0 = no priorities)
+        if (value < 0) return fail(c, VOLYM_E_INVALID, "priority thresholds: t1 + 100*t2 + 10000*t3, tenths of the fair share");
+        c->prio_tenths[0] = static_cast<uint32_t>(value % 100);
+        c->prio_tenths[1] = static_cast<uint32_t>((value / 100) % 100);
+        c->prio_tenths[2] = static_cast<uint32_t>(value / 10000);
         c->order_dirty = true;
         return VOLYM_OK;
     case 107:   // undocumented: 0 disables the 16x16 super fill items (A/B tests)
@@ -453,7 +461,17 @@ static int reorder_by_cost(volym_ctx* c)
     }
     std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first > b.first; });
     std::vector<uint32_t> order(keyed.size());
-    for (size_t i = 0; i < keyed.size(); ++i) order[i] = keyed[i].second;
+    // issue priority (bits 28-29) from the item's cost relative to a wave's fair share of the frame
+    const uint64_t fair = std::max<uint64_t>(1, total_cost / std::max(1u, resident_waves));
+    const bool prio_ok = c->prio_tenths[0] > 0 && static_cast<uint64_t>(c->n_local) * 16u < (1u << 28);
+    for (size_t i = 0; i < keyed.size(); ++i) {
+        uint32_t prio = 0;
+        if (prio_ok && keyed[i].first) {
+            const uint64_t k10 = static_cast<uint64_t>(keyed[i].first) * 10u;
+            prio = k10 >= c->prio_tenths[2] * fair ? 3u : k10 >= c->prio_tenths[1] * fair ? 2u : k10 >= c->prio_tenths[0] * fair ? 1u : 0u;
+        }
+        order[i] = keyed[i].second | (prio << 28);
+    }
     c->n_items = static_cast<uint32_t>(order.size());
     HIPCHK(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->order_by_cost = true;

@@ -148,9 +148,26 @@ __device__ __forceinline__ int floor_to_int(float x)
     return r;
 }
 
+// clamp(i, 0, hi) for hi >= 0 as one median-of-three
+__device__ __forceinline__ int clamp_texel(int i, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "v"(hi));
+    return r;
+}
+
+// a * b + c on the low 24 bits of a and b (full rate; the compiler's own choice for this pattern was the
+// quarter-rate 64-bit v_mad_u64_u32, whose register pair also tied independent loads together)
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b_uniform, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ int texel_nearest(float u, float fn, float hi)
 {
-    return min(max(floor_to_int(u * fn), 0), static_cast<int>(hi));
+    return clamp_texel(floor_to_int(u * fn), static_cast<int>(hi));
 }
 
 __device__ __forceinline__ uint32_t voxel_offset(const Grid& g, int ix, int iy, int iz)
@@ -159,7 +176,7 @@ __device__ __forceinline__ uint32_t voxel_offset(const Grid& g, int ix, int iy, 
     return bricked_offset(g.bx, g.bxy, static_cast<uint32_t>(ix), static_cast<uint32_t>(iy), static_cast<uint32_t>(iz));
 #else
     // x + nx*(y + ny*z) with two full-rate 24-bit multiplies: ny*z + y <= 4096*4095 + 4095 < 2^24 for every allowed size
-    return static_cast<uint32_t>(ix) + __umul24(static_cast<uint32_t>(g.nx), static_cast<uint32_t>(iy) + __umul24(static_cast<uint32_t>(g.ny), static_cast<uint32_t>(iz)));
+    return mad_u24(mad_u24(static_cast<uint32_t>(iz), static_cast<uint32_t>(g.ny), static_cast<uint32_t>(iy)), static_cast<uint32_t>(g.nx), static_cast<uint32_t>(ix));
 #endif
 }
 

@@ -87,8 +87,8 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
 {
     constexpr int K = TABLE ? KSPEC : 2;     // speculation depth (continuous-rho modes: 2 -- each sample is 5-8 gathers)
     unsigned long long trace_t0 = 0;
-    uint32_t trace_iters = 0, trace_flushes = 0, trace_tiles = 0, trace_marched = 0;
-    unsigned long long tm_leap = 0, tm_samp = 0, tm_flush = 0, tm_setup = 0, tm_mark = 0, tm_addr = 0, tm_wait = 0;
+    uint32_t trace_iters = 0, trace_flushes = 0, trace_tiles = 0, trace_marched = 0, trace_lanes = 0, trace_accepted = 0;
+    unsigned long long tm_leap = 0, tm_samp = 0, tm_flush = 0, tm_mark = 0;
 #define PQ_TICK() (TRACE ? __builtin_amdgcn_s_memtime() : 0ull)
     if (TRACE) trace_t0 = __builtin_amdgcn_s_memrealtime();
 
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     __shared__ float s_ic_alpha[256];
     __shared__ float s_rho[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_df[VOLYM_DF_LDS_BYTES];
-    __shared__ float s_qx[PQ_WAVES][PQ_QCAP], s_qy[PQ_WAVES][PQ_QCAP], s_qz[PQ_WAVES][PQ_QCAP], s_qw[PQ_WAVES][PQ_QCAP];
+    __shared__ float4 s_q[PQ_WAVES][PQ_QCAP];            // {pos, w}: one 16-byte LDS access per record
     __shared__ uint32_t s_qm[PQ_WAVES][PQ_QCAP];
     __shared__ float s_qr[TABLE ? 1 : PQ_WAVES][TABLE ? 1 : PQ_QCAP];
     __shared__ uint32_t s_acc[PQ_WAVES][3][64];
@@ -143,10 +143,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     Grid g;
     grid_init(g, vol, imp, fp.nx, fp.ny, fp.nz);
 
-    float* const qx = s_qx[wave];
-    float* const qy = s_qy[wave];
-    float* const qz = s_qz[wave];
-    float* const qw = s_qw[wave];
+    float4* const q4 = s_q[wave];
     uint32_t* const qm = s_qm[wave];
     float* const qr = s_qr[TABLE ? 0 : wave];
     uint32_t* const acc_r = s_acc[wave][0];
@@ -171,7 +168,16 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         // item = local_tile*4 + sub (an 8x8 wave tile, one lane per ray), or, for tiles the cost feedback
         // found expensive, bit 31 | (that id << 2) | quarter: a 4x4 quarter tile marched DEPTH-PARALLEL,
         // four lanes per ray, lane k of a quad taking the k-th speculative sample (see "dp" below)
-        const uint32_t raw0 = __builtin_amdgcn_readfirstlane(ticket < PQ_ITEMS_LDS ? s_items[ticket] : order[blockIdx.x + static_cast<size_t>(gridDim.x) * ticket]);
+        const uint32_t raw_p = __builtin_amdgcn_readfirstlane(ticket < PQ_ITEMS_LDS ? s_items[ticket] : order[blockIdx.x + static_cast<size_t>(gridDim.x) * ticket]);
+        // bits 28-29: issue priority the host derived from the measured cost.  The frame ends with its longest chains of
+        // dependent samples; a wave that carries one gets the SIMD's issue slots first, the cheap items fill the gaps.
+        switch ((raw_p >> 28) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+        const uint32_t raw0 = raw_p & ~0x30000000u;
         // bit 30 (bit 31 clear): a whole 16x16 tile that was constant in the frame the costs were measured on.  One
         // classification of the 16x16 rectangle and, if it still says "constant", 16-byte stores; otherwise its four
         // sub-tiles are processed here one after the other.
@@ -249,6 +255,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         uint32_t q_head = 0, q_count = 0;               // wave-uniform ring state
 
         Ray ray;
+        ray.o = v3(0.0f, 0.0f, 0.0f); ray.d = v3(0.0f, 0.0f, 0.0f); ray.t_entry = 0.0f; ray.t_exit = 0.0f;
         ray.hit = false;
         if (in_frame) ray = make_ray(fp, gx, gy);
         bool active = in_frame && ray.hit;
@@ -295,8 +302,9 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             __builtin_amdgcn_wave_barrier();
             if (lane < n) {
                 const uint32_t e = (q_head + lane) & (PQ_QCAP - 1);
-                const V3 pos = v3(qx[e], qy[e], qz[e]);
-                const float w = qw[e];
+                const float4 rec = q4[e];
+                const V3 pos = v3(rec.x, rec.y, rec.z);
+                const float w = rec.w;
                 const uint32_t meta = qm[e];
                 const uint32_t owner = meta & 63u, b = (meta >> 8) & 255u, ib = (meta >> 16) & 255u;
                 V3 color;
@@ -351,61 +359,58 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             if (mask == 0ull) return;
             if (emit) {
                 const uint32_t e = (q_head + q_count + lane_rank_in_mask(mask)) & (PQ_QCAP - 1);
-                qx[e] = p.x; qy[e] = p.y; qz[e] = p.z; qw[e] = w; qm[e] = meta;
+                q4[e] = make_float4(p.x, p.y, p.z, w); qm[e] = meta;
                 if (!TABLE) qr[e] = rho;
             }
             q_count += static_cast<uint32_t>(__popcll(mask));
             if (q_count >= 64u) flush(64u);
         };
 
-        if (TRACE) { const unsigned long long now = PQ_TICK(); tm_setup += now - tm_mark; tm_mark = now; }
+        if (TRACE) tm_mark = PQ_TICK();
         // ---- at most ONE leap per lane and iteration through provably empty macro cells (both march paths) ----
         auto leap_phase = [&]() {
             // at most ONE leap per lane and iteration through provably empty macro cells (see
             // raymarch_kernels.h VARIANT 1).  Cells with distance value < PQ_MIN_LEAP_D are simply sampled:
             // a one-cell leap replays ~3 steps, which the K-wide speculation below covers in the same
             // iteration without the ~100 instructions and the LDS round trip of a leap. ----
-            if (active) {
-                if (!(t < t_end && acc_a < 0.95f)) {              // wgsl:250 (t_end: nothing dense beyond)
-                    active = false;
-                } else if (!last_dense) {
-                    const V3 pos = ray.o + ray.d * t;
-                    const float cxf = __builtin_floorf(pos.x * mcf), cyf = __builtin_floorf(pos.y * mcf), czf = __builtin_floorf(pos.z * mcf);
-                    const int cx = static_cast<int>(cxf), cy = static_cast<int>(cyf), cz = static_cast<int>(czf);
-                    uint32_t D = 0;
-                    if (static_cast<uint32_t>(cx | cy | cz) < fp.mc_n) {
-                        const uint32_t ci = static_cast<uint32_t>(cx) + fp.mc_n * (static_cast<uint32_t>(cy) + fp.mc_n * static_cast<uint32_t>(cz));
-                        D = (static_cast<uint32_t>(s_df[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
-                    }
-                    if (D >= PQ_MIN_LEAP_D) {
-                        // smoothing taps sit up to 2*0.005 along the ray from the sample (wgsl:53-60): keep them inside too
-                        const float eps = gauss ? 4.0e-5f + 0.0101f : 4.0e-5f;
-                        const float a = static_cast<float>(D - 1u) * inv_mc - eps;
-                        const float lx = __builtin_fmaf(cxf, inv_mc, -a), hx = __builtin_fmaf(cxf, inv_mc, a + inv_mc);
-                        const float ly = __builtin_fmaf(cyf, inv_mc, -a), hy = __builtin_fmaf(cyf, inv_mc, a + inv_mc);
-                        const float lz = __builtin_fmaf(czf, inv_mc, -a), hz = __builtin_fmaf(czf, inv_mc, a + inv_mc);
-                        const float ex = __builtin_fmaxf(__builtin_fmaf(lx, idx_, nox), __builtin_fmaf(hx, idx_, nox));
-                        const float ey = __builtin_fmaxf(__builtin_fmaf(ly, idy_, noy), __builtin_fmaf(hy, idy_, noy));
-                        const float ez = __builtin_fmaxf(__builtin_fmaf(lz, idz_, noz), __builtin_fmaf(hz, idz_, noz));
-                        float te = __builtin_fminf(__builtin_fminf(ex, ey), ez);
-                        te = te - 2.0e-5f * __builtin_fabsf(te);
-                        // D >= 2: the cell of pos lies at least one whole cell inside the box, no `inside` test needed
-                        const float t_stop = __builtin_fminf(te, t_end);
-                        while (t < t_stop) {                          // replay of empty steps, wgsl:263-274
-                            if (COUNT) {
-                                n_steps++; n_imp++;
-                                if (gauss) {                          // the shader fetches the taps that lie inside [0,1]^3 (wgsl:58-66)
-                                    const V3 q = ray.o + ray.d * t;
-                                    for (int i = -2; i <= 2; ++i) if (!outside01(q + ray.d * (static_cast<float>(i) * 0.005f))) n_vol++;
-                                } else {
-                                    n_vol++;
-                                }
+            active = active && t < t_end && acc_a < 0.95f;            // wgsl:250 (t_end: nothing dense beyond)
+            {
+                // the cell lookup runs on every lane (clamped index, no branch); only D decides
+                const V3 pos = ray.o + ray.d * t;
+                const float cxf = __builtin_floorf(pos.x * mcf), cyf = __builtin_floorf(pos.y * mcf), czf = __builtin_floorf(pos.z * mcf);
+                const int cx = static_cast<int>(cxf), cy = static_cast<int>(cyf), cz = static_cast<int>(czf);
+                const bool in_range = static_cast<uint32_t>(cx | cy | cz) < fp.mc_n;
+                const uint32_t ci = in_range ? mad_u24(mad_u24(static_cast<uint32_t>(cz), fp.mc_n, static_cast<uint32_t>(cy)), fp.mc_n, static_cast<uint32_t>(cx)) : 0u;
+                uint32_t D = (static_cast<uint32_t>(s_df[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
+                if (!(active && !last_dense && in_range)) D = 0u;
+                if (D >= PQ_MIN_LEAP_D) {
+                    // smoothing taps sit up to 2*0.005 along the ray from the sample (wgsl:53-60): keep them inside too
+                    const float eps = gauss ? 4.0e-5f + 0.0101f : 4.0e-5f;
+                    const float a = static_cast<float>(D - 1u) * inv_mc - eps;
+                    const float lx = __builtin_fmaf(cxf, inv_mc, -a), hx = __builtin_fmaf(cxf, inv_mc, a + inv_mc);
+                    const float ly = __builtin_fmaf(cyf, inv_mc, -a), hy = __builtin_fmaf(cyf, inv_mc, a + inv_mc);
+                    const float lz = __builtin_fmaf(czf, inv_mc, -a), hz = __builtin_fmaf(czf, inv_mc, a + inv_mc);
+                    const float ex = __builtin_fmaxf(__builtin_fmaf(lx, idx_, nox), __builtin_fmaf(hx, idx_, nox));
+                    const float ey = __builtin_fmaxf(__builtin_fmaf(ly, idy_, noy), __builtin_fmaf(hy, idy_, noy));
+                    const float ez = __builtin_fmaxf(__builtin_fmaf(lz, idz_, noz), __builtin_fmaf(hz, idz_, noz));
+                    float te = __builtin_fminf(__builtin_fminf(ex, ey), ez);
+                    te = te - 2.0e-5f * __builtin_fabsf(te);
+                    // D >= 2: the cell of pos lies at least one whole cell inside the box, no `inside` test needed
+                    const float t_stop = __builtin_fminf(te, t_end);
+                    while (t < t_stop) {                          // replay of empty steps, wgsl:263-274
+                        if (COUNT) {
+                            n_steps++; n_imp++;
+                            if (gauss) {                          // the shader fetches the taps that lie inside [0,1]^3 (wgsl:58-66)
+                                const V3 q = ray.o + ray.d * t;
+                                for (int i = -2; i <= 2; ++i) if (!outside01(q + ray.d * (static_cast<float>(i) * 0.005f))) n_vol++;
+                            } else {
+                                n_vol++;
                             }
-                            cur = __builtin_fminf(base, cur * 1.5f);
-                            t += cur;
                         }
-                        if (!(t < t_end)) active = false;             // wgsl:250
+                        cur = __builtin_fminf(base, cur * 1.5f);
+                        t += cur;
                     }
+                    if (!(t < t_end)) active = false;             // wgsl:250
                 }
             }
 
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             const bool use_alpha_dp = imp_coloring || (flags & F_OPACITY) != 0u;
             while (__ballot(active) != 0ull) {
                 tile_iters++;
-                if (TRACE) { trace_iters++; tm_mark = PQ_TICK(); }
+                if (TRACE) { trace_iters++; trace_lanes += static_cast<uint32_t>(__popcll(__ballot(active))); tm_mark = PQ_TICK(); }
                 leap_phase();
                 if (TRACE) { const unsigned long long now = PQ_TICK(); tm_leap += now - tm_mark; tm_mark = now; }
                 // positions of the four speculative samples under "class stays last_dense" (wgsl:263-274)
@@ -480,6 +485,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                             }
                         }
                     }
+                    if (TRACE && kq == 0u) trace_accepted += static_cast<uint32_t>(last + 1);
                     if (last >= 0) {
                         const bool dl = ((quad_d >> last) & 1u) != 0u;
                         const float cur_before = last == 0 ? cur : (last == 1 ? cs4[0] : (last == 2 ? cs4[1] : cs4[2]));
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         } else {
         while (__ballot(active) != 0ull) {
             tile_iters++;
-            if (TRACE) { trace_iters++; tm_mark = PQ_TICK(); }
+            if (TRACE) { trace_iters++; trace_lanes += static_cast<uint32_t>(__popcll(__ballot(active))); tm_mark = PQ_TICK(); }
             leap_phase();
             if (TRACE) { const unsigned long long now = PQ_TICK(); tm_leap += now - tm_mark; tm_mark = now; }
             // ---- 2. K speculative samples: positions under the prediction "class stays last_dense" ----
@@ -515,13 +521,13 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                     cc = last_dense ? min_step : __builtin_fminf(base, cc * 1.5f);
                     tt += cc;
                 }
-                unsigned long long ta = 0;
-                if (TRACE) { ta = PQ_TICK(); tm_addr += ta - tm_mark; }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     bs[k] = 0; ibs[k] = 0; rhos[k] = 0.0f; taps[k] = 1;
+                    // the clamped texel selection keeps every offset inside the volume, whatever t is: the byte gathers
+                    // need no guard (a finished lane re-reads its last texels; nothing uses them)
+                    if (TABLE) bs[k] = vol[offs[k]];
                     if (active) {
-                        if (TABLE) bs[k] = vol[offs[k]];
                         if (need_imp) ibs[k] = imp[offs[k]];
                         if (!TABLE) {                                   // wgsl:253-259, all K densities in flight together
                             const V3 p = ray.o + ray.d * ts[k];
@@ -532,10 +538,37 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         }
                     }
                 }
-                if (TRACE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tm_wait += PQ_TICK() - ta; }
             }
 
             // ---- 3. accept samples in order with their real classes ----
+            if constexpr (TABLE && !COUNT && !IMP) {
+                // Straight-line form for the pinned flags (opacity on, no importance mode): the same decisions and the
+                // same f32 operations as the general form below, as selects instead of branches, and the K opacity
+                // look-ups issued together.
+                float a_tab[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) a_tab[k] = s_tf_tab[bs[k]].w;
+                const bool predicted = last_dense;
+                bool valid = active;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const bool go = valid && t < t_end && acc_a < 0.95f;             // wgsl:250
+                    const bool dense = bs[k] >= fp.thr_byte;                          // <=> b/255 >= thr
+                    const bool emit = go && dense;
+                    const float w = (1.0f - acc_a) * a_tab[k];                        // wgsl:313-318
+                    const V3 pos = ray.o + ray.d * t;                                 // == ps[k] while go
+                    acc_a = emit ? acc_a + w : acc_a;
+                    const float cur_next = dense ? min_step : __builtin_fminf(base, cur * 1.5f);   // wgsl:263-269
+                    cur = go ? cur_next : cur;
+                    t = go ? t + cur_next : t;                                        // wgsl:272, :325
+                    last_dense = go ? dense : last_dense;
+                    valid = go && dense == predicted;                                 // later speculative positions are off
+                    append(emit, pos, w, own | (bs[k] << 8), 0.0f);
+                }
+                active = active && t < t_end && acc_a < 0.95f;                        // wgsl:250, one iteration early
+                if (TRACE) tm_samp += PQ_TICK() - tm_mark;
+                continue;
+            }
             bool valid = active;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -544,6 +577,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 float w = 0.0f;
                 if (valid && !(t < t_end && acc_a < 0.95f)) { active = false; valid = false; }   // wgsl:250
                 if (valid) {
+                    if (TRACE) trace_accepted++;
                     if (COUNT) { n_steps++; n_imp++; }            // wgsl:260 fetches importance every step
                     pos = ray.o + ray.d * t;                      // t == ts[k] bit for bit while valid
                     bool dense;
@@ -622,12 +656,13 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
       }
     }
 
+    if (TRACE) for (int sft = 32; sft > 0; sft >>= 1) trace_accepted += __shfl_xor(trace_accepted, sft, 64);
     if (TRACE && lane == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
         const size_t rec = (static_cast<size_t>(blockIdx.x) * PQ_WAVES + wave) * 2u;
         trace[rec] = make_uint4(static_cast<uint32_t>(trace_t0), static_cast<uint32_t>(t1 - trace_t0), trace_iters | (trace_tiles << 16), trace_flushes | (trace_marched << 16));
         trace[rec + 1] = make_uint4(static_cast<uint32_t>(tm_leap >> 4), static_cast<uint32_t>((tm_samp - tm_flush) >> 4), static_cast<uint32_t>(tm_flush >> 4),
-                                    (static_cast<uint32_t>(tm_addr >> 8) & 0xffffu) | (static_cast<uint32_t>(tm_wait >> 8) << 16));
+                                    min(trace_lanes, 0xffffu) | (min(trace_accepted, 0xffffu) << 16));   // lanes active at the loop top, samples accepted
     }
     if (COUNT) {
         unsigned long long v[5] = {n_vol, n_imp, n_steps, n_dense, n_hit};
