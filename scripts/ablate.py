@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--feedback", type=int, nargs="*", default=[1])
     ap.add_argument("--dp", type=int, nargs="*", default=[-1])
     ap.add_argument("--prio", type=int, nargs="*", default=[100603])
+    ap.add_argument("--only-quarters", type=int, default=0)
+    ap.add_argument("--dev", type=int, nargs="*", default=[0])
     args = ap.parse_args()
     W, H = args.width, args.height
     dims = (256, 256, 256)
@@ -57,20 +59,24 @@ def main():
             for k in args.kernels:
                 for b, ks, cl, fb in [(b, ks, cl, fb) for b in (args.bands if k != 2 else args.wgs) for ks in (args.kspec if k == 2 else [1]) for cl in (args.cull if k == 2 else [1]) for fb in (args.feedback if k == 2 else [0])]:
                   for dpc, fine in [(d, f) for d in (args.dp if k == 2 else [0]) for f in (args.prio if k == 2 else [0])]:
+                   for dev in args.dev:
                     ctx.set_option(105, dpc)
                     ctx.set_option(108, fine)
+                    ctx.set_option(109, args.only_quarters)
                     ctx.set_option(102, ks)
                     ctx.set_option(103, cl)
                     ctx.set_option(104, fb)
                     ctx.set_option(_lib.OPT_KERNEL, k)
                     ctx.set_option(_lib.OPT_XCD_BANDS if k != 2 else 101, b)
                     ctx.update(cu, pu)
+                    ctx.set_option(110, dev)
                     ctx.time_passes(5)
                     ms = ctx.time_passes(args.n)
                     batch = 1e3 * ctx.time_batch(args.n) / args.n
                     st = ctx.stats_pass()
-                    print("%-6s kernel %d K%d cull%d fb%d dp%-4d prio%-6d bands %2d: %8.1f us (min %7.1f, batch %7.1f)  steps %10d dense %9d hit %8d" %
-                          (name, k, ks, cl, fb, dpc, fine, b, 1e3 * float(np.mean(ms)), 1e3 * float(ms.min()), batch, st["n_steps"], st["n_dense"], st["n_hit"]), flush=True)
+                    ctx.set_option(110, 0)
+                    print("dev%d %-6s kernel %d K%d cull%d fb%d dp%-4d prio%-6d bands %2d: %8.1f us (min %7.1f, batch %7.1f)  steps %10d dense %9d hit %8d" %
+                          (dev, name, k, ks, cl, fb, dpc, fine, b, 1e3 * float(np.mean(ms)), 1e3 * float(ms.min()), batch, st["n_steps"], st["n_dense"], st["n_hit"]), flush=True)
 
 
 if __name__ == "__main__":

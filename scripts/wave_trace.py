@@ -43,6 +43,16 @@ def main():
             n = L.volym_dev_wave_trace(ctx.handle, buf.ctypes.data_as(C.POINTER(C.c_uint32)), nrec)
             t_b = time.perf_counter()
             assert n > 0, n
+        L.volym_dev_read_costs.restype = C.c_int
+        L.volym_dev_read_costs.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.c_uint32]
+        L.volym_dev_read_order.restype = C.c_int
+        L.volym_dev_read_order.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+        ncost = ctx.local_tiles() * 4
+        cost = np.zeros(ncost, np.uint16)
+        assert L.volym_dev_read_costs(ctx.handle, cost.ctypes.data_as(C.POINTER(C.c_uint16)), ncost) == ncost
+        order = np.zeros(ncost * 4, np.uint32)
+        n_order = L.volym_dev_read_order(ctx.handle, order.ctypes.data_as(C.POINTER(C.c_uint32)), ncost * 4)
+        order = order[:n_order]
         print("host wall of the traced launch incl. memset+copy: %.1f us" % ((t_b - t_a) * 1e6))
         t_a = time.perf_counter(); ctx.stats_pass(); t_b = time.perf_counter()
         print("host wall of stats_pass: %.1f us ; event-timed plain pass %.1f us" % ((t_b - t_a) * 1e6, 1e3 * float(ctx.time_passes(20).mean())))
@@ -64,7 +74,7 @@ def main():
     print("end time us: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(end, q) / 100 for q in (10, 50, 90, 99, 100)))
     if args.kernel == 2:
         iters, tiles = r[:, 2] & 0xFFFF, r[:, 2] >> 16
-        flushes, marched = r[:, 3] & 0xFFFF, r[:, 3] >> 16
+        flushes, marched, dp_iters = r[:, 3] & 0xFFF, (r[:, 3] >> 12) & 15, r[:, 3] >> 16
         print("per wave: tiles mean %.1f max %d ; marched tiles mean %.2f max %d ; loop iterations mean %.1f max %d ; flushes mean %.1f max %d" % (
             tiles.mean(), tiles.max(), marched.mean(), marched.max(), iters.mean(), iters.max(), flushes.mean(), flushes.max()))
         print("totals: tiles %d marched %d iterations %d flushes %d" % (tiles.sum(), marched.sum(), iters.sum(), flushes.sum()))
@@ -87,6 +97,23 @@ def main():
         # per workgroup (16 waves): end time spread
         wg_end = end[: len(end) // 16 * 16].reshape(-1, 16).max(axis=1)
         print("workgroup end us: min %.1f p50 %.1f p90 %.1f max %.1f" % (wg_end.min() / 100, np.percentile(wg_end, 50) / 100, np.percentile(wg_end, 90) / 100, wg_end.max() / 100))
+        has_dp = dp_iters > 0
+        print("waves with depth-parallel items: %d ; their duration mean %.1f max %.1f us, dp iterations mean %.1f max %d, all iterations mean %.1f ; us per iteration %.2f" % (
+            has_dp.sum(), dur[has_dp].mean() / 100, dur[has_dp].max() / 100, dp_iters[has_dp].mean(), dp_iters[has_dp].max(), iters[has_dp].mean(), (dur[has_dp] / np.maximum(iters[has_dp], 1)).mean() / 100))
+        print("waves without: duration mean %.1f max %.1f us, iterations mean %.1f max %d" % (dur[~has_dp].mean() / 100, dur[~has_dp].max() / 100, iters[~has_dp].mean(), iters[~has_dp].max()))
+        sl = np.argsort(end)[-24:]
+        print("last 24 waves to end: end us %s\n   dur %s\n   iters %s\n   dp iters %s\n   flushes %s\n   tiles %s" % (
+            [round(float(x) / 100, 1) for x in end[sl]], [round(float(x) / 100, 1) for x in dur[sl]], iters[sl].tolist(), dp_iters[sl].tolist(), flushes[sl].tolist(), tiles[sl].tolist()))
+        # what the host predicted: cost share of every item of the list, dealt b, b+G, ...
+        G = 256
+        raw = order & ~np.uint32(0x30000000)
+        is_q = (raw >> 31) != 0
+        is_super = (~is_q) & ((raw >> 30) == 1)
+        item = np.where(is_q, (raw & 0x7fffffff) >> 2, raw) & 0x0fffffff
+        share = np.where(is_super, 0, np.where(is_q, (cost[np.minimum(item, ncost - 1)].astype(np.int64) + 3) // 4, cost[np.minimum(item, ncost - 1)].astype(np.int64)))
+        pred = np.array([share[b::G].sum() for b in range(G)], np.float64)
+        print("list: %d items, %d quarter items, %d super items; predicted cost per workgroup min %d p50 %d max %d ; first 12 shares %s ; prio counts %s" % (
+            n_order, is_q.sum(), is_super.sum(), pred.min(), np.percentile(pred, 50), pred.max(), list(share[:12]), np.bincount((order >> 28) & 3, minlength=4).tolist() if not is_q.any() else np.bincount(((order >> 28) & 3).astype(np.int64), minlength=4).tolist()))
         n16 = len(end) // 16 * 16
         wg_it = iters[:n16].reshape(-1, 16).sum(axis=1).astype(np.float64)
         wg_fl = flushes[:n16].reshape(-1, 16).sum(axis=1).astype(np.float64)
@@ -94,6 +121,8 @@ def main():
         wg_max_wave_it = iters[:n16].reshape(-1, 16).max(axis=1)
         print("per workgroup: iterations min %d p50 %d max %d ; flushes min %d p50 %d max %d ; busy wave-us min %.0f p50 %.0f max %.0f" % (
             wg_it.min(), np.percentile(wg_it, 50), wg_it.max(), wg_fl.min(), np.percentile(wg_fl, 50), wg_fl.max(), wg_busy.min(), np.percentile(wg_busy, 50), wg_busy.max()))
+        if len(wg_end) == G:
+            print("corr(predicted cost, traced 8*iterations+3*flushes) %.2f ; corr(predicted, end) %.2f" % (np.corrcoef(pred, 8 * wg_it + 3 * wg_fl)[0, 1], np.corrcoef(pred, wg_end)[0, 1]))
         print("corr(workgroup end, iterations) %.2f ; corr(end, flushes) %.2f ; corr(end, max wave iterations) %.2f ; corr(end, busy) %.2f" % (
             np.corrcoef(wg_end, wg_it)[0, 1], np.corrcoef(wg_end, wg_fl)[0, 1], np.corrcoef(wg_end, wg_max_wave_it)[0, 1], np.corrcoef(wg_end, wg_busy)[0, 1]))
         o = np.argsort(wg_end)

@@ -71,6 +71,7 @@ struct volym_ctx {
     bool feedback = true;
     bool super_fill = true;
     uint32_t prio_tenths[3] = {3, 6, 10};   // cost / fair share (tenths) from which an item runs at issue priority 1, 2, 3 (first 0: off)
+    bool dev_only_quarters = false;
     int dp_min_cost = -1;          // measured tile cost from which a tile is marched depth-parallel (0 = never, < 0 = adaptive)
     uint32_t n_items = 0;
     bool order_dirty = true;
@@ -222,7 +223,7 @@ int volym_set_option(volym_ctx* c, int key, int value)
         c->wgs_per_cu = static_cast<uint32_t>(value);
         return VOLYM_OK;
     case 102:   // undocumented tuning knob: speculation depth of variant 2 (1, 2 or 4)
-        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, VOLYM_E_INVALID, "speculation depth: 1, 2, 4 or 8");
+        if (value != 1 && value != 2 && value != 4) return fail(c, VOLYM_E_INVALID, "speculation depth: 1, 2 or 4");
         c->kspec = value;
         return VOLYM_OK;
     case 105:   // undocumented: measured cost from which tiles are marched depth-parallel (0 = never)
@@ -235,6 +236,13 @@ int volym_set_option(volym_ctx* c, int key, int value)
         c->prio_tenths[0] = static_cast<uint32_t>(value % 100);
         c->prio_tenths[1] = static_cast<uint32_t>((value / 100) % 100);
         c->prio_tenths[2] = static_cast<uint32_t>(value / 10000);
+        c->order_dirty = true;
+        return VOLYM_OK;
+    case 110:   // undocumented experiment: FrameParams::dev
+        c->fp.dev = static_cast<uint32_t>(value);
+        return VOLYM_OK;
+    case 109:   // undocumented experiment: keep only the depth-parallel items in the work list (the frame is then incomplete)
+        c->dev_only_quarters = value != 0;
         c->order_dirty = true;
         return VOLYM_OK;
     case 107:   // undocumented: 0 disables the 16x16 super fill items (A/B tests)
@@ -471,6 +479,11 @@ static int reorder_by_cost(volym_ctx* c)
             prio = k10 >= c->prio_tenths[2] * fair ? 3u : k10 >= c->prio_tenths[1] * fair ? 2u : k10 >= c->prio_tenths[0] * fair ? 1u : 0u;
         }
         order[i] = keyed[i].second | (prio << 28);
+    }
+    if (c->dev_only_quarters) {     // experiment: how long do the depth-parallel items take with the machine to themselves?
+        std::vector<uint32_t> q;
+        for (uint32_t o : order) if (o >> 31) q.push_back(o);
+        order.swap(q);
     }
     c->n_items = static_cast<uint32_t>(order.size());
     HIPCHK(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -732,11 +745,10 @@ static int launch_march(volym_ctx* c)
 #define VOLYM_PQ_LAUNCH(T, KS)                                                                                                   \
     hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT, TRACE, KS>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,  \
                        c->d_imp, c->d_tables, c->d_df, c->d_order, c->n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
-        const bool no_imp = !(fp.flags & (F_IMP_COLORING | F_IMP_RENDERING | F_WRITE_F32)) && (fp.flags & F_OPACITY) && (fp.flags & F_RASTER);
-        if (table && c->kspec == 4 && no_imp && !COUNT && !TRACE)
-            hipLaunchKernelGGL((volym_raymarch_pq_kernel<true, false, false, 4, false>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,
+        const bool no_imp = !(fp.flags & (F_IMP_COLORING | F_IMP_RENDERING)) && (fp.flags & F_OPACITY);
+        if (table && c->kspec == 4 && no_imp && !COUNT)
+            hipLaunchKernelGGL((volym_raymarch_pq_kernel<true, false, TRACE, 4, false>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,
                                c->d_imp, c->d_tables, c->d_df, c->d_order, c->n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp);
-        else if (table && c->kspec == 8) VOLYM_PQ_LAUNCH(true, 8);
         else if (table && c->kspec == 4) VOLYM_PQ_LAUNCH(true, 4);
         else if (table && c->kspec == 2) VOLYM_PQ_LAUNCH(true, 2);
         else if (table) VOLYM_PQ_LAUNCH(true, 1);
@@ -879,6 +891,17 @@ int volym_dev_read_costs(volym_ctx* c, uint16_t* out, uint32_t max_items)
     HIPCHK(c, hipMemcpyAsync(out, c->d_cost, n * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return static_cast<int>(n);
+}
+
+// Development aid: the work list as the kernel reads it (after cost feedback); returns the number of items.
+int volym_dev_read_order(volym_ctx* c, uint32_t* out, uint32_t max_items)
+{
+    if (!c || !out || !c->d_order) return VOLYM_E_INVALID;
+    if (max_items < c->n_items) return VOLYM_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_order, c->n_items * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return static_cast<int>(c->n_items);
 }
 
 // Development aid (not declared in the public header): one instrumented launch that records, per

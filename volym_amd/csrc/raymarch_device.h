@@ -53,7 +53,12 @@ struct FrameParams {
     float hull[2][8][4];     // [0] projected unit cube, [1] projected AABB of the occupied macro cells:
                              // up to 8 edges (a, b, c, valid) in pixel units, |(a,b)| = 1, inside: a*x + b*y + c >= 0
     float aabb_lo[3], aabb_hi[3];   // AABB of the occupied macro cells, already grown by its safety margin
+    uint32_t dev;            // timing experiments (VOLYM_DEV_SWITCHES): 1 = drop queued samples unshaded, 2 = never leap in dp items
 };
+
+#ifndef VOLYM_DEV_SWITCHES
+#define VOLYM_DEV_SWITCHES 1
+#endif
 
 enum : uint32_t {
     CULL_CUBE_HULL = 1u << 0,   // hull[0] is usable (every cube corner in front of the eye)

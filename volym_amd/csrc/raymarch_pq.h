@@ -45,8 +45,11 @@ namespace volym {
 constexpr int PQ_WAVES = 16;             // waves per workgroup
 constexpr int PQ_THREADS = PQ_WAVES * 64;
 constexpr uint32_t PQ_MIN_LEAP_D = 2;    // smallest distance-field value worth a leap
+constexpr int PQ_DP_DEPTH = 2;           // depth-parallel items: samples per lane and iteration (4 lanes per ray)
 constexpr int PQ_ITEMS_LDS = 512;       // work-list entries staged in LDS per workgroup (the rest stay in global memory)
-constexpr int PQ_QCAP = 128;             // ring entries per wave (>= 64 queued + 64 new)
+// ring entries per wave: < 64 left over from the last iteration + 64 per speculative sample of this one.  One workgroup
+// per CU owns the whole 160 KB of LDS, so the queue is sized for the shading to run at ONE point of the loop.
+constexpr int pq_qcap(int k) { return 64 + 64 * k; }
 constexpr float PQ_FIX_SCALE = 268435456.0f;        // 2^28
 constexpr float PQ_FIX_INV = 1.0f / 268435456.0f;
 
@@ -86,8 +89,10 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     Counters* __restrict__ counters, uint4* __restrict__ trace, const FrameParams fp)
 {
     constexpr int K = TABLE ? KSPEC : 2;     // speculation depth (continuous-rho modes: 2 -- each sample is 5-8 gathers)
+    constexpr int PQ_QCAP = pq_qcap(K);
+    static_assert(K <= 4, "the shading queue of K > 4 does not fit the LDS");
     unsigned long long trace_t0 = 0;
-    uint32_t trace_iters = 0, trace_flushes = 0, trace_tiles = 0, trace_marched = 0, trace_lanes = 0, trace_accepted = 0;
+    uint32_t trace_iters = 0, trace_flushes = 0, trace_tiles = 0, trace_marched = 0, trace_lanes = 0, trace_accepted = 0, trace_dp_iters = 0;
     unsigned long long tm_leap = 0, tm_samp = 0, tm_flush = 0, tm_mark = 0;
 #define PQ_TICK() (TRACE ? __builtin_amdgcn_s_memtime() : 0ull)
     if (TRACE) trace_t0 = __builtin_amdgcn_s_memrealtime();
@@ -104,9 +109,9 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     __shared__ uint32_t s_next_ticket;
     __shared__ uint32_t s_items[PQ_ITEMS_LDS];          // this workgroup's work list (items b, b+G, ...)
 
-    // IMP = false also pins the other frame-constant flags of the common case (opacity on, raster output, no float
-    // side buffer) so that their tests fold away; every other combination runs the IMP = true instantiation
-    const uint32_t flags = IMP ? fp.flags : ((fp.flags & ~(F_IMP_COLORING | F_IMP_RENDERING | F_CONE | F_WRITE_F32)) | F_OPACITY | F_RASTER);
+    // IMP = false also pins the opacity flag of the common case so that its tests fold away; every other combination
+    // runs the IMP = true instantiation
+    const uint32_t flags = IMP ? fp.flags : ((fp.flags & ~(F_IMP_COLORING | F_IMP_RENDERING | F_CONE)) | F_OPACITY);
     const bool linear = (flags & F_LINEAR) != 0u;
     const bool gauss = (flags & F_GAUSSIAN) != 0u;
     // IMP = false: instantiation for frames with both importance modes off (the reference's "Base" rows): the
@@ -300,8 +305,8 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             if (TRACE) { trace_flushes++; fl0 = PQ_TICK(); }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lane < n) {
-                const uint32_t e = (q_head + lane) & (PQ_QCAP - 1);
+            if (lane < n && !(VOLYM_DEV_SWITCHES && (fp.dev & 1u))) {
+                const uint32_t e0 = q_head + lane, e = min(e0, e0 - PQ_QCAP);      // ring wrap (unsigned)
                 const float4 rec = q4[e];
                 const V3 pos = v3(rec.x, rec.y, rec.z);
                 const float w = rec.w;
@@ -346,7 +351,8 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 atomicAdd(&acc_g[owner], static_cast<uint32_t>(__builtin_fmaf(shaded.y * w, PQ_FIX_SCALE, 0.5f)));
                 atomicAdd(&acc_b[owner], static_cast<uint32_t>(__builtin_fmaf(shaded.z * w, PQ_FIX_SCALE, 0.5f)));
             }
-            q_head = (q_head + n) & (PQ_QCAP - 1);
+            q_head += n;
+            if (q_head >= PQ_QCAP) q_head -= PQ_QCAP;
             q_count -= n;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -358,13 +364,16 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             const unsigned long long mask = __ballot(emit);
             if (mask == 0ull) return;
             if (emit) {
-                const uint32_t e = (q_head + q_count + lane_rank_in_mask(mask)) & (PQ_QCAP - 1);
+                const uint32_t e0 = q_head + q_count + lane_rank_in_mask(mask), e = min(e0, e0 - PQ_QCAP);
                 q4[e] = make_float4(p.x, p.y, p.z, w); qm[e] = meta;
                 if (!TABLE) qr[e] = rho;
             }
             q_count += static_cast<uint32_t>(__popcll(mask));
-            if (q_count >= 64u) flush(64u);
         };
+        // Shading happens at one point of an iteration: right after the byte gathers of the next samples were issued,
+        // so that the latency of those gathers and the shading of the previous samples overlap (the long chains of
+        // dependent samples are what a frame ends on).
+        auto drain = [&]() { while (q_count >= 64u) flush(64u); };
 
         if (TRACE) tm_mark = PQ_TICK();
         // ---- at most ONE leap per lane and iteration through provably empty macro cells (both march paths) ----
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             // a one-cell leap replays ~3 steps, which the K-wide speculation below covers in the same
             // iteration without the ~100 instructions and the LDS round trip of a leap. ----
             active = active && t < t_end && acc_a < 0.95f;            // wgsl:250 (t_end: nothing dense beyond)
-            {
+            if (__ballot(active && !last_dense) != 0ull) {              // inside a dense run nobody can leap
                 // the cell lookup runs on every lane (clamped index, no branch); only D decides
                 const V3 pos = ray.o + ray.d * t;
                 const float cxf = __builtin_floorf(pos.x * mcf), cyf = __builtin_floorf(pos.y * mcf), czf = __builtin_floorf(pos.z * mcf);
@@ -422,10 +431,81 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             // samples.  All state (t, cur, alpha, last_dense) is replicated in the quad and updated by the
             // same arithmetic in every lane, so the accepted samples are those of the sequential march.
             const uint32_t kq = lane & 3u, qsh = lane & 60u;
+            if constexpr (!IMP) {
+                // Pinned flags (opacity on, no importance mode): PQ_DP_DEPTH samples per lane, i.e. 4 * PQ_DP_DEPTH
+                // speculative samples per ray and iteration, sample s on lane s & 3.  These items are the frame's longest
+                // chains of dependent samples (grazing rays that stay within a cell of a surface, or inside it): what
+                // matters for them is samples per iteration, and a long run of one class is exactly what they consist of.
+                constexpr int J = PQ_DP_DEPTH;
+                while (__ballot(active) != 0ull) {
+                    tile_iters++;
+                    if (TRACE) { trace_iters++; trace_dp_iters++; trace_lanes += static_cast<uint32_t>(__popcll(__ballot(active))); tm_mark = PQ_TICK(); }
+                    if (VOLYM_DEV_SWITCHES && (fp.dev & 2u)) active = active && t < t_end && acc_a < 0.95f;
+                    else leap_phase();
+                    if (TRACE) { const unsigned long long now = PQ_TICK(); tm_leap += now - tm_mark; tm_mark = now; }
+                    // predicted positions (class stays last_dense, wgsl:263-274); this lane keeps samples kq, kq + 4, ...
+                    float my_t[J];
+                    {
+                        float tt = t, cc = cur;
+#pragma unroll
+                        for (int sidx = 0; sidx < 4 * J; ++sidx) {
+                            if ((sidx & 3) == 0) my_t[sidx >> 2] = tt;
+                            else my_t[sidx >> 2] = kq == static_cast<uint32_t>(sidx & 3) ? tt : my_t[sidx >> 2];
+                            cc = last_dense ? min_step : __builtin_fminf(base, cc * 1.5f);
+                            tt += cc;
+                        }
+                    }
+                    V3 my_pos[J];
+                    uint32_t my_b[J];
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        my_pos[j] = ray.o + ray.d * my_t[j];               // wgsl:251
+                        my_b[j] = vol[nearest_offset(g, my_pos[j])];        // clamped offset: no guard needed
+                    }
+                    drain();
+                    uint32_t quad_d[J];
+                    float a4[J][4];
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        quad_d[j] = static_cast<uint32_t>(__ballot(my_b[j] >= fp.thr_byte) >> qsh) & 15u;   // <=> b/255 >= thr
+                        const int a_bits = __float_as_int(s_tf_tab[my_b[j]].w);
+                        a4[j][0] = __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0x00, 0xf, 0xf, true));
+                        a4[j][1] = __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0x55, 0xf, 0xf, true));
+                        a4[j][2] = __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0xaa, 0xf, 0xf, true));
+                        a4[j][3] = __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0xff, 0xf, 0xf, true));
+                    }
+                    // the sequential march over the 4J samples, identical in the four lanes of a quad
+                    const bool predicted = last_dense;
+                    bool valid = active;
+                    bool my_emit[J];
+                    float my_w[J];
+#pragma unroll
+                    for (int sidx = 0; sidx < 4 * J; ++sidx) {
+                        const int j = sidx >> 2, k = sidx & 3;
+                        const bool go = valid && t < t_end && acc_a < 0.95f;         // wgsl:250
+                        const bool dense = ((quad_d[j] >> k) & 1u) != 0u;
+                        const bool emit = go && dense;
+                        const float w = (1.0f - acc_a) * a4[j][k];                    // wgsl:313-318
+                        if (k == 0) { my_emit[j] = emit; my_w[j] = w; }
+                        else if (kq == static_cast<uint32_t>(k)) { my_emit[j] = emit; my_w[j] = w; }
+                        acc_a = emit ? acc_a + w : acc_a;
+                        const float cur_next = dense ? min_step : __builtin_fminf(base, cur * 1.5f);   // wgsl:263-269
+                        cur = go ? cur_next : cur;
+                        t = go ? t + cur_next : t;                                    // wgsl:272, :325
+                        last_dense = go ? dense : last_dense;
+                        valid = go && dense == predicted;                             // later speculative positions are off
+                        if (TRACE && kq == 0u && go) trace_accepted++;
+                    }
+                    active = active && t < t_end && acc_a < 0.95f;
+#pragma unroll
+                    for (int j = 0; j < J; ++j) append(my_emit[j], my_pos[j], my_w[j], own | (my_b[j] << 8), 0.0f);
+                    if (TRACE) tm_samp += PQ_TICK() - tm_mark;
+                }
+            } else {
             const bool use_alpha_dp = imp_coloring || (flags & F_OPACITY) != 0u;
             while (__ballot(active) != 0ull) {
                 tile_iters++;
-                if (TRACE) { trace_iters++; trace_lanes += static_cast<uint32_t>(__popcll(__ballot(active))); tm_mark = PQ_TICK(); }
+                if (TRACE) { trace_iters++; trace_dp_iters++; trace_lanes += static_cast<uint32_t>(__popcll(__ballot(active))); tm_mark = PQ_TICK(); }
                 leap_phase();
                 if (TRACE) { const unsigned long long now = PQ_TICK(); tm_leap += now - tm_mark; tm_mark = now; }
                 // positions of the four speculative samples under "class stays last_dense" (wgsl:263-274)
@@ -443,11 +523,9 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 const float tk = kq == 0u ? ts4[0] : (kq == 1u ? ts4[1] : (kq == 2u ? ts4[2] : ts4[3]));
                 const V3 pos = ray.o + ray.d * tk;                    // wgsl:251
                 const uint32_t off = nearest_offset(g, pos);
-                uint32_t b = 0, ib = 0;
-                if (active) {
-                    b = vol[off];
-                    if (need_imp) ib = imp[off];
-                }
+                uint32_t b = vol[off], ib = 0;                         // clamped offset: no guard needed
+                if (active && need_imp) ib = imp[off];
+                drain();
                 const bool dense_k = b >= fp.thr_byte;                // <=> b/255 >= thr
                 const float a_k = imp_coloring ? s_ic_alpha[ib] : s_tf_tab[b].w;
                 const uint32_t quad_d = static_cast<uint32_t>(__ballot(dense_k) >> qsh) & 15u;
@@ -500,6 +578,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 append(my_emit, pos, my_w, own | (b << 8) | (ib << 16), 0.0f);
                 if (TRACE) tm_samp += PQ_TICK() - tm_mark;
             }
+            }
         } else {
         while (__ballot(active) != 0ull) {
             tile_iters++;
@@ -539,6 +618,8 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                     }
                 }
             }
+
+            drain();
 
             // ---- 3. accept samples in order with their real classes ----
             if constexpr (TABLE && !COUNT && !IMP) {
@@ -632,6 +713,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             if (TRACE) tm_samp += PQ_TICK() - tm_mark;
         }
         }
+        drain();
         if (q_count) flush(q_count);
 
         // ---- store (wgsl:328-329; rgba8unorm) ----
@@ -660,7 +742,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     if (TRACE && lane == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
         const size_t rec = (static_cast<size_t>(blockIdx.x) * PQ_WAVES + wave) * 2u;
-        trace[rec] = make_uint4(static_cast<uint32_t>(trace_t0), static_cast<uint32_t>(t1 - trace_t0), trace_iters | (trace_tiles << 16), trace_flushes | (trace_marched << 16));
+        trace[rec] = make_uint4(static_cast<uint32_t>(trace_t0), static_cast<uint32_t>(t1 - trace_t0), trace_iters | (trace_tiles << 16), min(trace_flushes, 0xfffu) | (min(trace_marched, 15u) << 12) | (min(trace_dp_iters, 0xffffu) << 16));
         trace[rec + 1] = make_uint4(static_cast<uint32_t>(tm_leap >> 4), static_cast<uint32_t>((tm_samp - tm_flush) >> 4), static_cast<uint32_t>(tm_flush >> 4),
                                     min(trace_lanes, 0xffffu) | (min(trace_accepted, 0xffffu) << 16));   // lanes active at the loop top, samples accepted
     }
