@@ -62,12 +62,22 @@ enum : uint32_t { TILE_MARCH = 0, TILE_HIT_TEST = 1, TILE_FILL_EMPTY = 2, TILE_F
 
 // Classify the pixel rectangle [x0, x0+extent] x [y0, y0+extent] against the two projected hulls (wave-uniform
 // result; lane l evaluates hull l>>5, edge (l>>2)&7, corner l&3).
-__device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, uint32_t lane, float x0, float y0, float extent = 7.0f)
+// The lane's edge (a, b, c, valid) is fetched once per kernel (HullEdge): indexing the kernel arguments by lane is a
+// memory gather, and a fill tile is little else.
+struct HullEdge { float a, b, c; bool valid; };
+__device__ __forceinline__ HullEdge load_hull_edge(const FrameParams& fp, uint32_t lane)
 {
-    const uint32_t h = lane >> 5, e = (lane >> 2) & 7u, k = lane & 3u;
+    const uint32_t h = lane >> 5, e = (lane >> 2) & 7u;
+    HullEdge r;
+    r.a = fp.hull[h][e][0]; r.b = fp.hull[h][e][1]; r.c = fp.hull[h][e][2]; r.valid = fp.hull[h][e][3] > 0.5f;
+    return r;
+}
+__device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, const HullEdge& edge, uint32_t lane, float x0, float y0, float extent = 7.0f)
+{
+    const uint32_t k = lane & 3u;
     const float cx = (k & 1u) ? x0 + extent : x0, cy = (k & 2u) ? y0 + extent : y0;
-    const float a = fp.hull[h][e][0], b = fp.hull[h][e][1], c = fp.hull[h][e][2];
-    const bool valid = fp.hull[h][e][3] > 0.5f;
+    const float a = edge.a, b = edge.b, c = edge.c;
+    const bool valid = edge.valid;
     const float v = __builtin_fmaf(a, cx, __builtin_fmaf(b, cy, c));
     const float margin = 1.5f;
     const unsigned long long mo = __ballot(valid && v < -margin);     // corner strictly outside edge
@@ -120,6 +130,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     const bool imp_rendering = IMP && (flags & F_IMP_RENDERING) != 0u;
     const bool need_imp = imp_coloring || imp_rendering;
 
+    if (VOLYM_DEV_SWITCHES && (fp.dev & 16u)) return;                    // launch + dispatch only
     {
         const uint32_t i = threadIdx.x;
         if (i == 0u) s_next_ticket = 0u;
@@ -137,10 +148,12 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             const uint32_t n16 = (fp.mc_n * fp.mc_n * fp.mc_n / 2u + 15u) / 16u;
             const uint4* src = reinterpret_cast<const uint4*>(df4);
             uint4* dst = reinterpret_cast<uint4*>(s_df);
-            for (uint32_t k = i; k < n16; k += PQ_THREADS) dst[k] = src[k];
+            if (!(VOLYM_DEV_SWITCHES && (fp.dev & 8u)))
+                for (uint32_t k = i; k < n16; k += PQ_THREADS) dst[k] = src[k];
         }
     }
     __syncthreads();
+    if (VOLYM_DEV_SWITCHES && (fp.dev & 4u)) return;                     // ... + staging
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -168,6 +181,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         return __builtin_amdgcn_readfirstlane(ticket);
     };
     const bool culling = !COUNT && fp.cull != 0u;
+    const HullEdge hull_edge = load_hull_edge(fp, lane);
     for (uint32_t ticket = grab(); ticket < n_mine; ticket = grab()) {
       {
         // item = local_tile*4 + sub (an 8x8 wave tile, one lane per ray), or, for tiles the cost feedback
@@ -192,12 +206,15 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             const uint32_t lt = raw0 & 0x3fffffffu;
             const uint32_t tile16 = lt * fp.world + fp.rank;
             const uint32_t tx16 = tile16 % fp.tiles_x, ty16 = tile16 / fp.tiles_x;
-            const uint32_t cls = culling ? classify_tile(fp, lane, static_cast<float>(tx16 * 16u), static_cast<float>(ty16 * 16u), 15.0f) : TILE_MARCH;
+            const uint32_t cls = culling ? classify_tile(fp, hull_edge, lane, static_cast<float>(tx16 * 16u), static_cast<float>(ty16 * 16u), 15.0f) : TILE_MARCH;
             if (cls >= TILE_FILL_EMPTY) {
                 const uint32_t packed = cls == TILE_FILL_MISS ? 0xff000000u : 0u;
                 if (flags & F_RASTER) {
                     const uint32_t gx4 = tx16 * 16u + (lane & 3u) * 4u, gy4 = ty16 * 16u + (lane >> 2);
-                    if (gy4 < fp.H) {
+                    if (gy4 < fp.H && (fp.W & 3u) == 0u && (reinterpret_cast<uintptr_t>(out_raster) & 15u) == 0u && gx4 < fp.W && !(flags & F_WRITE_F32)) {
+                        // rows are 16-byte aligned: one store per lane
+                        *reinterpret_cast<uint4*>(out_raster + static_cast<size_t>(gy4) * fp.W + gx4) = make_uint4(packed, packed, packed, packed);
+                    } else if (gy4 < fp.H) {
                         for (uint32_t i = 0; i < 4u; ++i)
                             if (gx4 + i < fp.W) {
                                 out_raster[static_cast<size_t>(gy4) * fp.W + gx4 + i] = packed;
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         uint32_t tile_iters = 0, tile_flushes = 0;      // measured cost of this tile, fed back to the scheduler
         uint32_t tclass = TILE_MARCH;
         if (culling && !dp) {
-            tclass = classify_tile(fp, lane, static_cast<float>(tx * 16u + ((sub & 1u) << 3)), static_cast<float>(ty * 16u + ((sub >> 1) << 3)));
+            tclass = classify_tile(fp, hull_edge, lane, static_cast<float>(tx * 16u + ((sub & 1u) << 3)), static_cast<float>(ty * 16u + ((sub >> 1) << 3)));
             if (tclass >= TILE_FILL_EMPTY) {            // no ray of this tile can differ from the constant
                 const uint32_t packed = tclass == TILE_FILL_MISS ? 0xff000000u : 0u;     // (0,0,0,1) wgsl:239 / (0,0,0,0) wgsl:328
                 if (flags & F_RASTER) {
@@ -437,18 +454,24 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 // chains of dependent samples (grazing rays that stay within a cell of a surface, or inside it): what
                 // matters for them is samples per iteration, and a long run of one class is exactly what they consist of.
                 constexpr int J = PQ_DP_DEPTH;
+                bool try_leap = true;
+                active = active && t < t_end;
                 while (__ballot(active) != 0ull) {
                     tile_iters++;
                     if (TRACE) { trace_iters++; trace_dp_iters++; trace_lanes += static_cast<uint32_t>(__popcll(__ballot(active))); tm_mark = PQ_TICK(); }
-                    if (VOLYM_DEV_SWITCHES && (fp.dev & 2u)) active = active && t < t_end && acc_a < 0.95f;
-                    else leap_phase();
+                    // a leap is worth looking for only where the march just ran through a whole batch of non-dense samples
+                    // (or has not sampled yet); `active` is up to date either way
+                    if (try_leap && !(VOLYM_DEV_SWITCHES && (fp.dev & 2u))) leap_phase();
                     if (TRACE) { const unsigned long long now = PQ_TICK(); tm_leap += now - tm_mark; tm_mark = now; }
-                    // predicted positions (class stays last_dense, wgsl:263-274); this lane keeps samples kq, kq + 4, ...
-                    float my_t[J];
+                    // predicted march under "class stays last_dense" (wgsl:263-274): position of sample s and the step
+                    // size in force before it; this lane fetches samples kq, kq + 4, ...
+                    constexpr int N = 4 * J;
+                    float ts[N], cb[N], my_t[J];
                     {
                         float tt = t, cc = cur;
 #pragma unroll
-                        for (int sidx = 0; sidx < 4 * J; ++sidx) {
+                        for (int sidx = 0; sidx < N; ++sidx) {
+                            ts[sidx] = tt; cb[sidx] = cc;
                             if ((sidx & 3) == 0) my_t[sidx >> 2] = tt;
                             else my_t[sidx >> 2] = kq == static_cast<uint32_t>(sidx & 3) ? tt : my_t[sidx >> 2];
                             cc = last_dense ? min_step : __builtin_fminf(base, cc * 1.5f);
@@ -459,43 +482,63 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                     uint32_t my_b[J];
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
-                        my_pos[j] = ray.o + ray.d * my_t[j];               // wgsl:251
+                        my_pos[j] = ray.o + ray.d * my_t[j];                 // wgsl:251
                         my_b[j] = vol[nearest_offset(g, my_pos[j])];        // clamped offset: no guard needed
                     }
                     drain();
-                    uint32_t quad_d[J];
+                    uint32_t cm = 0;                                         // class bits of the N samples (same in the quad)
                     float a4[J][4];
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
-                        quad_d[j] = static_cast<uint32_t>(__ballot(my_b[j] >= fp.thr_byte) >> qsh) & 15u;   // <=> b/255 >= thr
+                        cm |= (static_cast<uint32_t>(__ballot(my_b[j] >= fp.thr_byte) >> qsh) & 15u) << (4 * j);   // <=> b/255 >= thr
                         const int a_bits = __float_as_int(s_tf_tab[my_b[j]].w);
                         a4[j][0] = __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0x00, 0xf, 0xf, true));
                         a4[j][1] = __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0x55, 0xf, 0xf, true));
                         a4[j][2] = __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0xaa, 0xf, 0xf, true));
                         a4[j][3] = __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0xff, 0xf, 0xf, true));
                     }
-                    // the sequential march over the 4J samples, identical in the four lanes of a quad
-                    const bool predicted = last_dense;
-                    bool valid = active;
-                    bool my_emit[J];
-                    float my_w[J];
+                    // How many samples does the sequential march accept?  It stops (wgsl:250) at the first sample with
+                    // t >= t_end or alpha >= 0.95, and the predicted positions hold up to and including the first sample
+                    // whose class differs from the prediction.  t and alpha grow monotonically, so the three limits are
+                    // counts.  Alpha is the reference's own recurrence (wgsl:313-318), applied to the dense samples.
+                    uint32_t n_t = 0, n_a = 0;
+                    float a_run = acc_a, a_after[N], my_w[J];
 #pragma unroll
-                    for (int sidx = 0; sidx < 4 * J; ++sidx) {
-                        const int j = sidx >> 2, k = sidx & 3;
-                        const bool go = valid && t < t_end && acc_a < 0.95f;         // wgsl:250
-                        const bool dense = ((quad_d[j] >> k) & 1u) != 0u;
-                        const bool emit = go && dense;
-                        const float w = (1.0f - acc_a) * a4[j][k];                    // wgsl:313-318
-                        if (k == 0) { my_emit[j] = emit; my_w[j] = w; }
-                        else if (kq == static_cast<uint32_t>(k)) { my_emit[j] = emit; my_w[j] = w; }
-                        acc_a = emit ? acc_a + w : acc_a;
-                        const float cur_next = dense ? min_step : __builtin_fminf(base, cur * 1.5f);   // wgsl:263-269
-                        cur = go ? cur_next : cur;
-                        t = go ? t + cur_next : t;                                    // wgsl:272, :325
-                        last_dense = go ? dense : last_dense;
-                        valid = go && dense == predicted;                             // later speculative positions are off
-                        if (TRACE && kq == 0u && go) trace_accepted++;
+                    for (int sidx = 0; sidx < N; ++sidx) {
+                        n_t += ts[sidx] < t_end ? 1u : 0u;
+                        n_a += a_run < 0.95f ? 1u : 0u;
+                        const float w = (1.0f - a_run) * a4[sidx >> 2][sidx & 3];
+                        if ((sidx & 3) == 0) my_w[sidx >> 2] = w;
+                        else my_w[sidx >> 2] = kq == static_cast<uint32_t>(sidx & 3) ? w : my_w[sidx >> 2];
+                        a_run = ((cm >> sidx) & 1u) ? a_run + w : a_run;
+                        a_after[sidx] = a_run;
                     }
+                    const uint32_t full = (1u << N) - 1u;
+                    const uint32_t mism = cm ^ (last_dense ? full : 0u);
+                    const uint32_t n_c = min(static_cast<uint32_t>(__builtin_ctz(mism | (1u << N))) + 1u, static_cast<uint32_t>(N));
+                    const uint32_t n_acc = min(min(n_t, n_a), n_c);          // >= 1 on an active lane
+                    const uint32_t em = active ? (cm & ((1u << n_acc) - 1u)) : 0u;   // accepted dense samples emit
+                    bool my_emit[J];
+#pragma unroll
+                    for (int j = 0; j < J; ++j) my_emit[j] = ((em >> (4 * j + kq)) & 1u) != 0u;
+                    if (TRACE && kq == 0u && active) trace_accepted += n_acc;
+                    // state after the last accepted sample
+                    const uint32_t last = n_acc - 1u;
+                    float t_sel = ts[0], cb_sel = cb[0], a_sel = a_after[0];
+#pragma unroll
+                    for (int sidx = 1; sidx < N; ++sidx) {
+                        const bool ge = last >= static_cast<uint32_t>(sidx);
+                        t_sel = ge ? ts[sidx] : t_sel; cb_sel = ge ? cb[sidx] : cb_sel; a_sel = ge ? a_after[sidx] : a_sel;
+                    }
+                    const bool dl = ((cm >> last) & 1u) != 0u;
+                    const float cur_new = dl ? min_step : __builtin_fminf(base, cb_sel * 1.5f);    // wgsl:263-269 with the real class
+                    if (active) {
+                        cur = cur_new;
+                        t = t_sel + cur_new;                                  // wgsl:272, :325
+                        acc_a = a_sel;
+                        last_dense = dl;
+                    }
+                    try_leap = __ballot(active && !dl && n_acc == static_cast<uint32_t>(N)) != 0ull;
                     active = active && t < t_end && acc_a < 0.95f;
 #pragma unroll
                     for (int j = 0; j < J; ++j) append(my_emit[j], my_pos[j], my_w[j], own | (my_b[j] << 8), 0.0f);
