@@ -394,13 +394,18 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
 
         if (TRACE) tm_mark = PQ_TICK();
         // ---- at most ONE leap per lane and iteration through provably empty macro cells (both march paths) ----
+        // Looking for a leap costs ~100 instructions and an LDS round trip per iteration.  A ray that has just sampled
+        // its way through a whole batch of non-dense samples (or has not sampled yet) is in open space and may find one; a
+        // ray whose last batch met the object is within a cell of it, where the distance field says "sample".
+        bool leap_ok = true;
         auto leap_phase = [&]() {
             // at most ONE leap per lane and iteration through provably empty macro cells (see
             // raymarch_kernels.h VARIANT 1).  Cells with distance value < PQ_MIN_LEAP_D are simply sampled:
             // a one-cell leap replays ~3 steps, which the K-wide speculation below covers in the same
             // iteration without the ~100 instructions and the LDS round trip of a leap. ----
             active = active && t < t_end && acc_a < 0.95f;            // wgsl:250 (t_end: nothing dense beyond)
-            if (__ballot(active && !last_dense) != 0ull) {              // inside a dense run nobody can leap
+            const bool want_leap = active && !last_dense && leap_ok;
+            if (__ballot(want_leap) != 0ull) {                          // inside a dense run nobody can leap
                 // the cell lookup runs on every lane (clamped index, no branch); only D decides
                 const V3 pos = ray.o + ray.d * t;
                 const float cxf = __builtin_floorf(pos.x * mcf), cyf = __builtin_floorf(pos.y * mcf), czf = __builtin_floorf(pos.z * mcf);
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 const bool in_range = static_cast<uint32_t>(cx | cy | cz) < fp.mc_n;
                 const uint32_t ci = in_range ? mad_u24(mad_u24(static_cast<uint32_t>(cz), fp.mc_n, static_cast<uint32_t>(cy)), fp.mc_n, static_cast<uint32_t>(cx)) : 0u;
                 uint32_t D = (static_cast<uint32_t>(s_df[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
-                if (!(active && !last_dense && in_range)) D = 0u;
+                if (!(want_leap && in_range)) D = 0u;
                 if (D >= PQ_MIN_LEAP_D) {
                     // smoothing taps sit up to 2*0.005 along the ray from the sample (wgsl:53-60): keep them inside too
                     const float eps = gauss ? 4.0e-5f + 0.0101f : 4.0e-5f;
@@ -531,6 +536,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         t_sel = ge ? ts[sidx] : t_sel; cb_sel = ge ? cb[sidx] : cb_sel; a_sel = ge ? a_after[sidx] : a_sel;
                     }
                     const bool dl = ((cm >> last) & 1u) != 0u;
+                    const bool last_dense_before = last_dense;
                     const float cur_new = dl ? min_step : __builtin_fminf(base, cb_sel * 1.5f);    // wgsl:263-269 with the real class
                     if (active) {
                         cur = cur_new;
@@ -538,7 +544,8 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         acc_a = a_sel;
                         last_dense = dl;
                     }
-                    try_leap = __ballot(active && !dl && n_acc == static_cast<uint32_t>(N)) != 0ull;
+                    leap_ok = !dl && !last_dense_before && n_acc == static_cast<uint32_t>(N);
+                    try_leap = __ballot(active && leap_ok) != 0ull;
                     active = active && t < t_end && acc_a < 0.95f;
 #pragma unroll
                     for (int j = 0; j < J; ++j) append(my_emit[j], my_pos[j], my_w[j], own | (my_b[j] << 8), 0.0f);
@@ -687,6 +694,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                     t = go ? t + cur_next : t;                                        // wgsl:272, :325
                     last_dense = go ? dense : last_dense;
                     valid = go && dense == predicted;                                 // later speculative positions are off
+                    if (k == K - 1) leap_ok = go && !dense && !predicted;
                     append(emit, pos, w, own | (bs[k] << 8), 0.0f);
                 }
                 active = active && t < t_end && acc_a < 0.95f;                        // wgsl:250, one iteration early
