@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--prio", type=int, nargs="*", default=[100603])
     ap.add_argument("--only-quarters", type=int, default=0)
     ap.add_argument("--dev", type=int, nargs="*", default=[0])
+    ap.add_argument("--balance", type=int, default=20050)
     args = ap.parse_args()
     W, H = args.width, args.height
     dims = (256, 256, 256)
@@ -63,6 +64,7 @@ def main():
                     ctx.set_option(105, dpc)
                     ctx.set_option(108, fine)
                     ctx.set_option(109, args.only_quarters)
+                    ctx.set_option(111, args.balance)
                     ctx.set_option(102, ks)
                     ctx.set_option(103, cl)
                     ctx.set_option(104, fb)

@@ -106,11 +106,12 @@ def main():
             [round(float(x) / 100, 1) for x in end[sl]], [round(float(x) / 100, 1) for x in dur[sl]], iters[sl].tolist(), dp_iters[sl].tolist(), flushes[sl].tolist(), tiles[sl].tolist()))
         # what the host predicted: cost share of every item of the list, dealt b, b+G, ...
         G = 256
-        raw = order & ~np.uint32(0x30000000)
+        pad = order == 0xFFFFFFFF
+        raw = np.where(pad, 0, order & ~np.uint32(0x30000000)).astype(np.uint32)
         is_q = (raw >> 31) != 0
         is_super = (~is_q) & ((raw >> 30) == 1)
         item = np.where(is_q, (raw & 0x7fffffff) >> 2, raw) & 0x0fffffff
-        share = np.where(is_super, 0, np.where(is_q, (cost[np.minimum(item, ncost - 1)].astype(np.int64) + 3) // 4, cost[np.minimum(item, ncost - 1)].astype(np.int64)))
+        share = np.where(is_super | pad, 0, np.where(is_q, (cost[np.minimum(item, ncost - 1)].astype(np.int64) + 3) // 4, cost[np.minimum(item, ncost - 1)].astype(np.int64)))
         pred = np.array([share[b::G].sum() for b in range(G)], np.float64)
         print("list: %d items, %d quarter items, %d super items; predicted cost per workgroup min %d p50 %d max %d ; first 12 shares %s ; prio counts %s" % (
             n_order, is_q.sum(), is_super.sum(), pred.min(), np.percentile(pred, 50), pred.max(), list(share[:12]), np.bincount((order >> 28) & 3, minlength=4).tolist() if not is_q.any() else np.bincount(((order >> 28) & 3).astype(np.int64), minlength=4).tolist()))

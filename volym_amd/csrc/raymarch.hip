@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <queue>
 #include <vector>
 
 #include "../../include/volym_hip.h"
@@ -72,6 +73,10 @@ struct volym_ctx {
     bool super_fill = true;
     uint32_t prio_tenths[3] = {3, 6, 10};   // cost / fair share (tenths) from which an item runs at issue priority 1, 2, 3 (first 0: off)
     bool dev_only_quarters = false;
+    size_t order_capacity = 0;     // entries d_order can hold
+    uint32_t order_grid = 0;       // workgroups the cost-ordered list was dealt to (0: the geometric list, any grid)
+    uint32_t dp_share_pct = 60;    // a quarter item's wave time as a percentage of the time its tile took as one item
+    uint32_t fill_cost = 2;        // cost units charged for a constant 8x8 tile when balancing
     int dp_min_cost = -1;          // measured tile cost from which a tile is marched depth-parallel (0 = never, < 0 = adaptive)
     uint32_t n_items = 0;
     bool order_dirty = true;
@@ -241,6 +246,11 @@ int volym_set_option(volym_ctx* c, int key, int value)
     case 110:   // undocumented experiment: FrameParams::dev
         c->fp.dev = static_cast<uint32_t>(value);
         return VOLYM_OK;
+    case 111:   // undocumented: balancing estimates, dp_share_pct + 1000 * fill_cost
+        c->dp_share_pct = static_cast<uint32_t>(value % 1000);
+        c->fill_cost = static_cast<uint32_t>(value / 1000);
+        c->order_dirty = true;
+        return VOLYM_OK;
     case 109:   // undocumented experiment: keep only the depth-parallel items in the work list (the frame is then incomplete)
         c->dev_only_quarters = value != 0;
         c->order_dirty = true;
@@ -409,7 +419,9 @@ static int build_order(volym_ctx* c)
     if (c->d_cost) { HIPCHK(c, hipFree(c->d_cost)); c->d_cost = nullptr; }
     c->n_items = static_cast<uint32_t>(order.size());
     if (c->n_items) {
-        hipError_t e = hipMalloc(&c->d_order, order.size() * 4 * sizeof(uint32_t));   // room for quarter-tile items
+        c->order_capacity = order.size() * 4;
+        c->order_grid = 0;
+        hipError_t e = hipMalloc(&c->d_order, c->order_capacity * sizeof(uint32_t));   // room for quarter-tile items
         if (e == hipSuccess) e = hipMalloc(&c->d_cost, static_cast<size_t>(c->n_local) * 4 * sizeof(uint16_t));
         if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(order): ") + hipGetErrorString(e));
         HIPCHK(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -442,7 +454,7 @@ static int reorder_by_cost(volym_ctx* c)
     for (uint32_t item : c->h_order) total_cost += cost[item];
     const uint32_t resident_waves = static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu * PQ_WAVES;
     // dp_min_cost < 0 encodes the factor in tenths (-20 = 2.0 x fair share, the default -1 means 2.0)
-    const uint64_t tenths = c->dp_min_cost < -1 ? static_cast<uint64_t>(-c->dp_min_cost) : 20u;
+    const uint64_t tenths = c->dp_min_cost < -1 ? static_cast<uint64_t>(-c->dp_min_cost) : 15u;
     const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(64, tenths * total_cost / (10u * std::max(1u, resident_waves)) + 16));
     const uint32_t dp_thr = c->dp_min_cost < 0 ? adaptive : static_cast<uint32_t>(c->dp_min_cost);
     const bool dp_ok = c->dp_min_cost != 0 && !(c->fp.flags & (F_LINEAR | F_GAUSSIAN | F_IMP_RENDERING));
@@ -463,29 +475,58 @@ static int reorder_by_cost(volym_ctx* c)
             continue;
         }
         if (dp_ok && k >= dp_thr)
-            for (uint32_t qd = 0; qd < 4; ++qd) keyed.emplace_back((k + 3u) / 4u, 0x80000000u | (item << 2) | qd);
+            for (uint32_t qd = 0; qd < 4; ++qd) keyed.emplace_back((k * c->dp_share_pct + 99u) / 100u, 0x80000000u | (item << 2) | qd);
         else
             keyed.emplace_back(k, item);
     }
     std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first > b.first; });
-    std::vector<uint32_t> order(keyed.size());
+    if (c->dev_only_quarters) {     // experiment: how long do the depth-parallel items take with the machine to themselves?
+        std::vector<std::pair<uint32_t, uint32_t>> q;
+        for (const auto& kv : keyed) if (kv.second >> 31) q.push_back(kv);
+        keyed.swap(q);
+    }
     // issue priority (bits 28-29) from the item's cost relative to a wave's fair share of the frame
     const uint64_t fair = std::max<uint64_t>(1, total_cost / std::max(1u, resident_waves));
     const bool prio_ok = c->prio_tenths[0] > 0 && static_cast<uint64_t>(c->n_local) * 16u < (1u << 28);
-    for (size_t i = 0; i < keyed.size(); ++i) {
-        uint32_t prio = 0;
-        if (prio_ok && keyed[i].first) {
-            const uint64_t k10 = static_cast<uint64_t>(keyed[i].first) * 10u;
-            prio = k10 >= c->prio_tenths[2] * fair ? 3u : k10 >= c->prio_tenths[1] * fair ? 2u : k10 >= c->prio_tenths[0] * fair ? 1u : 0u;
+    // Workgroup b reads items b, b + G, ... of the list.  The lists are filled longest-processing-time first: every item,
+    // in order of decreasing cost, goes to the workgroup with the least work so far, so the sums differ by less than one
+    // item; shorter lists are padded with PQ_NO_ITEM.
+    const uint32_t n_keyed = static_cast<uint32_t>(keyed.size());
+    const uint32_t G = std::max(1u, std::min((n_keyed + PQ_WAVES - 1) / PQ_WAVES, static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu));
+    std::vector<std::vector<uint32_t>> lists(G);
+    {
+        typedef std::pair<uint64_t, uint32_t> Load;      // (work so far, workgroup)
+        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+        for (uint32_t b = 0; b < G; ++b) heap.emplace(0u, b);
+        for (const auto& kv : keyed) {
+            uint32_t prio = 0;
+            if (prio_ok && kv.first) {
+                const uint64_t k10 = static_cast<uint64_t>(kv.first) * 10u;
+                prio = k10 >= c->prio_tenths[2] * fair ? 3u : k10 >= c->prio_tenths[1] * fair ? 2u : k10 >= c->prio_tenths[0] * fair ? 1u : 0u;
+            }
+            Load l = heap.top();
+            heap.pop();
+            lists[l.second].push_back(kv.second | (prio << 28));
+            // constant tiles were measured as 0: a store of 64 or 256 pixels is not free
+            const uint32_t floor_share = ((kv.second >> 30) == 1u) ? c->fill_cost * 3u : c->fill_cost;
+            l.first += std::max(kv.first, floor_share);
+            heap.push(l);
         }
-        order[i] = keyed[i].second | (prio << 28);
     }
-    if (c->dev_only_quarters) {     // experiment: how long do the depth-parallel items take with the machine to themselves?
-        std::vector<uint32_t> q;
-        for (uint32_t o : order) if (o >> 31) q.push_back(o);
-        order.swap(q);
+    size_t maxlen = 0;
+    for (const auto& l : lists) maxlen = std::max(maxlen, l.size());
+    std::vector<uint32_t> order(static_cast<size_t>(G) * maxlen, PQ_NO_ITEM);
+    for (uint32_t b = 0; b < G; ++b)
+        for (size_t i = 0; i < lists[b].size(); ++i) order[b + static_cast<size_t>(G) * i] = lists[b][i];
+    if (order.size() > c->order_capacity) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->d_order));
+        c->d_order = nullptr;
+        HIPCHK(c, hipMalloc(&c->d_order, order.size() * sizeof(uint32_t)));
+        c->order_capacity = order.size();
     }
     c->n_items = static_cast<uint32_t>(order.size());
+    c->order_grid = G;
     HIPCHK(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->order_by_cost = true;
     return VOLYM_OK;
@@ -740,7 +781,7 @@ static int launch_march(volym_ctx* c)
         uint16_t* cost_out = (plain && c->feedback && !c->order_by_cost) ? c->d_cost : nullptr;
         if (plain) c->frames_since_change++;
         const uint32_t want = (c->n_items + PQ_WAVES - 1) / PQ_WAVES;
-        const uint32_t pgrid = std::max(1u, std::min(want, static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu));
+        const uint32_t pgrid = c->order_grid ? c->order_grid : std::max(1u, std::min(want, static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu));
         const bool table = !(fp.flags & (F_LINEAR | F_GAUSSIAN));
 #define VOLYM_PQ_LAUNCH(T, KS)                                                                                                   \
     hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT, TRACE, KS>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,  \

@@ -46,6 +46,7 @@ constexpr int PQ_WAVES = 16;             // waves per workgroup
 constexpr int PQ_THREADS = PQ_WAVES * 64;
 constexpr uint32_t PQ_MIN_LEAP_D = 2;    // smallest distance-field value worth a leap
 constexpr int PQ_DP_DEPTH = 2;           // depth-parallel items: samples per lane and iteration (4 lanes per ray)
+constexpr uint32_t PQ_NO_ITEM = 0xffffffffu;   // padding of the work list
 constexpr int PQ_ITEMS_LDS = 512;       // work-list entries staged in LDS per workgroup (the rest stay in global memory)
 // ring entries per wave: < 64 left over from the last iteration + 64 per speculative sample of this one.  One workgroup
 // per CU owns the whole 160 KB of LDS, so the queue is sized for the shading to run at ONE point of the loop.
@@ -67,9 +68,20 @@ enum : uint32_t { TILE_MARCH = 0, TILE_HIT_TEST = 1, TILE_FILL_EMPTY = 2, TILE_F
 struct HullEdge { float a, b, c; bool valid; };
 __device__ __forceinline__ HullEdge load_hull_edge(const FrameParams& fp, uint32_t lane)
 {
-    const uint32_t h = lane >> 5, e = (lane >> 2) & 7u;
+    // 16 uniform reads and selects: indexing the by-value argument struct with the lane would make the compiler keep
+    // a copy of it in scratch memory
+    const uint32_t mine = lane >> 2;
+    float a = 0.0f, b = 0.0f, c = 0.0f, v = 0.0f;
+#pragma unroll
+    for (uint32_t i = 0; i < 16u; ++i) {
+        const bool m = mine == i;
+        a = m ? fp.hull[i >> 3][i & 7u][0] : a;
+        b = m ? fp.hull[i >> 3][i & 7u][1] : b;
+        c = m ? fp.hull[i >> 3][i & 7u][2] : c;
+        v = m ? fp.hull[i >> 3][i & 7u][3] : v;
+    }
     HullEdge r;
-    r.a = fp.hull[h][e][0]; r.b = fp.hull[h][e][1]; r.c = fp.hull[h][e][2]; r.valid = fp.hull[h][e][3] > 0.5f;
+    r.a = a; r.b = b; r.c = c; r.valid = v > 0.5f;
     return r;
 }
 __device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, const HullEdge& edge, uint32_t lane, float x0, float y0, float extent = 7.0f)
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
 
     // ---- work distribution: this workgroup owns items b, b+G, ...; its waves draw them in order ----
     const uint32_t n_mine = n_items > blockIdx.x ? (n_items - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
-    auto grab = [&]() -> uint32_t {
+    auto grab = [&]() __attribute__((always_inline)) -> uint32_t {
         uint32_t ticket = 0;
         if (lane == 0) ticket = atomicAdd(&s_next_ticket, 1u);
         return __builtin_amdgcn_readfirstlane(ticket);
@@ -188,6 +200,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         // found expensive, bit 31 | (that id << 2) | quarter: a 4x4 quarter tile marched DEPTH-PARALLEL,
         // four lanes per ray, lane k of a quad taking the k-th speculative sample (see "dp" below)
         const uint32_t raw_p = __builtin_amdgcn_readfirstlane(ticket < PQ_ITEMS_LDS ? s_items[ticket] : order[blockIdx.x + static_cast<size_t>(gridDim.x) * ticket]);
+        if (raw_p == PQ_NO_ITEM) continue;
         // bits 28-29: issue priority the host derived from the measured cost.  The frame ends with its longest chains of
         // dependent samples; a wave that carries one gets the SIMD's issue slots first, the cheap items fill the gaps.
         switch ((raw_p >> 28) & 3u) {
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         const bool in_frame = gx < fp.W && gy < fp.H;   // wgsl:217-219
 
         if (TRACE) { trace_tiles++; tm_mark = PQ_TICK(); }
-        uint32_t tile_iters = 0, tile_flushes = 0;      // measured cost of this tile, fed back to the scheduler
+        uint32_t tile_iters = 0, tile_flushes = 0, tile_trips = 0;   // deterministic cost of this tile, fed back to the scheduler
         uint32_t tclass = TILE_MARCH;
         if (culling && !dp) {
             tclass = classify_tile(fp, hull_edge, lane, static_cast<float>(tx * 16u + ((sub & 1u) << 3)), static_cast<float>(ty * 16u + ((sub >> 1) << 3)));
@@ -307,6 +320,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 // replay of the empty steps in front of the AABB (wgsl:263-274), cur == base throughout
                 const float t_first = __builtin_fminf(tn, t_end);
                 while (t < t_first) {
+                    tile_trips++;
                     cur = __builtin_fminf(base, cur * 1.5f);
                     t += cur;
                 }
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         const float nox = -ray.o.x * idx_, noy = -ray.o.y * idy_, noz = -ray.o.z * idz_;
 
         // ---- shade up to 64 queued samples, one per lane (COLOUR arithmetic) ----
-        auto flush = [&](uint32_t n) {
+        auto flush = [&](uint32_t n) __attribute__((always_inline)) {
             unsigned long long fl0 = 0;
             tile_flushes++;
             if (TRACE) { trace_flushes++; fl0 = PQ_TICK(); }
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         };
 
         // ---- push the samples flagged by `emit` (any subset of lanes), shade when 64 are waiting ----
-        auto append = [&](bool emit, V3 p, float w, uint32_t meta, float rho) {
+        auto append = [&](bool emit, V3 p, float w, uint32_t meta, float rho) __attribute__((always_inline)) {
             const unsigned long long mask = __ballot(emit);
             if (mask == 0ull) return;
             if (emit) {
@@ -386,11 +400,12 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 if (!TABLE) qr[e] = rho;
             }
             q_count += static_cast<uint32_t>(__popcll(mask));
+            if (!TABLE && q_count >= 64u) flush(64u);      // continuous-rho modes shade as soon as a batch is full (see drain)
         };
         // Shading happens at one point of an iteration: right after the byte gathers of the next samples were issued,
         // so that the latency of those gathers and the shading of the previous samples overlap (the long chains of
         // dependent samples are what a frame ends on).
-        auto drain = [&]() { while (q_count >= 64u) flush(64u); };
+        auto drain = [&]() __attribute__((always_inline)) { while (q_count >= 64u) flush(64u); };
 
         if (TRACE) tm_mark = PQ_TICK();
         // ---- at most ONE leap per lane and iteration through provably empty macro cells (both march paths) ----
@@ -398,7 +413,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         // its way through a whole batch of non-dense samples (or has not sampled yet) is in open space and may find one; a
         // ray whose last batch met the object is within a cell of it, where the distance field says "sample".
         bool leap_ok = true;
-        auto leap_phase = [&]() {
+        auto leap_phase = [&]() __attribute__((always_inline)) {
             // at most ONE leap per lane and iteration through provably empty macro cells (see
             // raymarch_kernels.h VARIANT 1).  Cells with distance value < PQ_MIN_LEAP_D are simply sampled:
             // a one-cell leap replays ~3 steps, which the K-wide speculation below covers in the same
@@ -429,6 +444,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                     // D >= 2: the cell of pos lies at least one whole cell inside the box, no `inside` test needed
                     const float t_stop = __builtin_fminf(te, t_end);
                     while (t < t_stop) {                          // replay of empty steps, wgsl:263-274
+                        tile_trips++;
                         if (COUNT) {
                             n_steps++; n_imp++;
                             if (gauss) {                          // the shader fetches the taps that lie inside [0,1]^3 (wgsl:58-66)
@@ -462,7 +478,6 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 bool try_leap = true;
                 active = active && t < t_end;
                 while (__ballot(active) != 0ull) {
-                    tile_iters++;
                     if (TRACE) { trace_iters++; trace_dp_iters++; trace_lanes += static_cast<uint32_t>(__popcll(__ballot(active))); tm_mark = PQ_TICK(); }
                     // a leap is worth looking for only where the march just ran through a whole batch of non-dense samples
                     // (or has not sampled yet); `active` is up to date either way
@@ -554,7 +569,6 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             } else {
             const bool use_alpha_dp = imp_coloring || (flags & F_OPACITY) != 0u;
             while (__ballot(active) != 0ull) {
-                tile_iters++;
                 if (TRACE) { trace_iters++; trace_dp_iters++; trace_lanes += static_cast<uint32_t>(__popcll(__ballot(active))); tm_mark = PQ_TICK(); }
                 leap_phase();
                 if (TRACE) { const unsigned long long now = PQ_TICK(); tm_leap += now - tm_mark; tm_mark = now; }
@@ -669,7 +683,9 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 }
             }
 
-            drain();
+            // table mode: shade here, while the byte gathers are in flight; the continuous-rho modes shade at the end of
+            // the iteration instead, where the K densities are no longer live (their shading alone needs ~100 registers)
+            if (TABLE) drain();
 
             // ---- 3. accept samples in order with their real classes ----
             if constexpr (TABLE && !COUNT && !IMP) {
@@ -782,7 +798,9 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         } else if (!in_frame && !(flags & F_RASTER) && (!dp || (lane & 3u) == 0u)) {
             out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + sub_lane] = 0u;
         }
-        if (cost && !dp && lane == 0) cost[item] = static_cast<uint16_t>(min(65535u, 1u + tile_iters * 8u + tile_flushes * 3u));
+        // cost of the tile as the scheduler sees it, in units of ~56 instructions: ray set-up, loop iterations, shading
+        // batches, replayed steps (counted, not timed: the work list must not depend on the weather)
+        if (cost && !dp && lane == 0) cost[item] = static_cast<uint16_t>(min(65535u, 5u + tile_iters * 5u + tile_flushes * 2u + tile_trips / 7u));
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
