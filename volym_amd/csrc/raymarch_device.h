@@ -364,6 +364,43 @@ __device__ __forceinline__ V3 blinn_phong(V3 color, V3 grad, V3 pos, V3 eye)
     return v3(__builtin_fmaf(color.x, kd, ks), __builtin_fmaf(color.y, kd, ks), __builtin_fmaf(color.z, kd, ks));
 }
 
+// t += base, repeated until t >= t_stop, without the repetitions: the exact f32 recurrence of the empty-space steps once
+// the step size has reached `base` (wgsl:263-274 with cur == base).  Inside one binade t = m * u (u = ulp, m a 24-bit
+// integer) and fl(t + base) = (m + K) * u with the same K = round(base / u) at every step, unless base / u lies exactly
+// halfway between two integers (ties go to the even mantissa, which alternates).  So n steps inside a binade are one
+// integer multiply-add; the step that crosses into the next binade, ties, and tiny t are single real additions.
+__device__ __forceinline__ void replay_saturated(float& t, float t_stop, float base)
+{
+    while (t < t_stop) {
+        const uint32_t tb = __float_as_uint(t);
+        const uint32_t ex = tb >> 23;                                    // biased exponent (t > 0)
+        const float inv_u = __uint_as_float((277u - ex) << 23);          // 2^(150 - ex) = 1 / ulp(t)
+        const float q = base * inv_u;                                    // exact: a power-of-two scaling
+        const float kf = __builtin_rintf(q);
+        if (ex < 100u || !(q < 4194304.0f) || __builtin_fabsf(q - kf) == 0.5f || !(kf >= 1.0f)) {   // tiny t, huge or tiny step, tie
+            t += base;
+            continue;
+        }
+        const uint32_t m = (tb & 0x7fffffu) | 0x800000u;
+        const uint32_t K = static_cast<uint32_t>(kf);
+        const float xs = t_stop * inv_u;                                 // exact scaling; >= 2^24: not in this binade
+        const uint32_t lim = xs < 16777216.0f ? static_cast<uint32_t>(__builtin_ceilf(xs)) : 0x1000000u;   // first mantissa >= t_stop
+        const uint32_t need = lim - m;                                   // >= 1 because t < t_stop
+        uint32_t n = static_cast<uint32_t>(static_cast<float>(need) * __builtin_amdgcn_rcpf(kf));
+        if (n * K < need) n++;                                           // n = ceil(need / K): quotients are small, one fix-up suffices
+        if (n * K < need) n++;
+        if (m + n * K >= 0x1000000u) {
+            // the n-th step leaves the binade: n - 1 steps in closed form, then one real addition
+            const uint32_t m2 = m + (n - 1u) * K;
+            t = __uint_as_float((tb & 0xff800000u) | (m2 & 0x7fffffu));
+            t += base;
+        } else {
+            const uint32_t m2 = m + n * K;
+            t = __uint_as_float((tb & 0xff800000u) | (m2 & 0x7fffffu)); // >= t_stop
+        }
+    }
+}
+
 // rgba8unorm store: clamp, scale, round to nearest
 __device__ __forceinline__ uint32_t to_unorm8(float v)
 {

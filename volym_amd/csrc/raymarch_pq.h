@@ -59,6 +59,8 @@ __device__ __forceinline__ uint32_t lane_rank_in_mask(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 enum : uint32_t { TILE_MARCH = 0, TILE_HIT_TEST = 1, TILE_FILL_EMPTY = 2, TILE_FILL_MISS = 3 };
 
 // Classify the pixel rectangle [x0, x0+extent] x [y0, y0+extent] against the two projected hulls (wave-uniform
@@ -301,7 +303,8 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         float t_end = ray.t_exit;                        // samples at t >= t_end cannot be dense
         if (culling && (fp.cull & CULL_AABB) && active) {
             // slab test against the AABB of the occupied macro cells (conservative arithmetic)
-            const float rx = 1.0f / ray.d.x, ry = 1.0f / ray.d.y, rz = 1.0f / ray.d.z;
+            // v_rcp_f32 (1 ulp) instead of a division: the slab distances carry a 2e-5 margin
+            const float rx = __builtin_amdgcn_rcpf(ray.d.x), ry = __builtin_amdgcn_rcpf(ray.d.y), rz = __builtin_amdgcn_rcpf(ray.d.z);
             const float ax0 = (fp.aabb_lo[0] - ray.o.x) * rx, ax1 = (fp.aabb_hi[0] - ray.o.x) * rx;
             const float ay0 = (fp.aabb_lo[1] - ray.o.y) * ry, ay1 = (fp.aabb_hi[1] - ray.o.y) * ry;
             const float az0 = (fp.aabb_lo[2] - ray.o.z) * rz, az1 = (fp.aabb_hi[2] - ray.o.z) * rz;
@@ -319,14 +322,10 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 t_end = __builtin_fminf(t_end, tf);
                 // replay of the empty steps in front of the AABB (wgsl:263-274), cur == base throughout
                 const float t_first = __builtin_fminf(tn, t_end);
-                while (t < t_first) {
-                    tile_trips++;
-                    cur = __builtin_fminf(base, cur * 1.5f);
-                    t += cur;
-                }
+                replay_saturated(t, t_first, base);
             }
         }
-        const float idx_ = 1.0f / ray.d.x, idy_ = 1.0f / ray.d.y, idz_ = 1.0f / ray.d.z;
+        const float idx_ = __builtin_amdgcn_rcpf(ray.d.x), idy_ = __builtin_amdgcn_rcpf(ray.d.y), idz_ = __builtin_amdgcn_rcpf(ray.d.z);   // leap exits carry a margin too
         const float nox = -ray.o.x * idx_, noy = -ray.o.y * idy_, noz = -ray.o.z * idz_;
 
         // ---- shade up to 64 queued samples, one per lane (COLOUR arithmetic) ----
@@ -360,9 +359,12 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 if (TABLE) {
                     const int ix = texel_nearest(pos.x, g.fnx, g.hix), iy = texel_nearest(pos.y, g.fny, g.hiy),
                               iz = texel_nearest(pos.z, g.fnz, g.hiz);
-                    const int ixp = texel_nearest(pos.x + o, g.fnx, g.hix), ixm = texel_nearest(pos.x - o, g.fnx, g.hix);
-                    const int iyp = texel_nearest(pos.y + o, g.fny, g.hiy), iym = texel_nearest(pos.y - o, g.fny, g.hiy);
-                    const int izp = texel_nearest(pos.z + o, g.fnz, g.hiz), izm = texel_nearest(pos.z - o, g.fnz, g.hiz);
+                    // the +o / -o taps of an axis as one packed add and one packed multiply (same IEEE operations per component)
+                    const f32x2 pm = {o, -o};
+                    const f32x2 uxs = (pos.x + pm) * g.fnx, uys = (pos.y + pm) * g.fny, uzs = (pos.z + pm) * g.fnz;
+                    const int ixp = clamp_texel(floor_to_int(uxs.x), static_cast<int>(g.hix)), ixm = clamp_texel(floor_to_int(uxs.y), static_cast<int>(g.hix));
+                    const int iyp = clamp_texel(floor_to_int(uys.x), static_cast<int>(g.hiy)), iym = clamp_texel(floor_to_int(uys.y), static_cast<int>(g.hiy));
+                    const int izp = clamp_texel(floor_to_int(uzs.x), static_cast<int>(g.hiz)), izm = clamp_texel(floor_to_int(uzs.y), static_cast<int>(g.hiz));
                     const int bxp = vol[voxel_offset(g, ixp, iy, iz)], bxm = vol[voxel_offset(g, ixm, iy, iz)];
                     const int byp = vol[voxel_offset(g, ix, iyp, iz)], bym = vol[voxel_offset(g, ix, iym, iz)];
                     const int bzp = vol[voxel_offset(g, ix, iy, izp)], bzm = vol[voxel_offset(g, ix, iy, izm)];
@@ -443,8 +445,16 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                     te = te - 2.0e-5f * __builtin_fabsf(te);
                     // D >= 2: the cell of pos lies at least one whole cell inside the box, no `inside` test needed
                     const float t_stop = __builtin_fminf(te, t_end);
-                    while (t < t_stop) {                          // replay of empty steps, wgsl:263-274
+                    if (!COUNT) {
+                        // replay of empty steps, wgsl:263-274: at most four until the step size is back at `base`, the rest in closed form
+                        while (cur < base && t < t_stop) {
+                            cur = __builtin_fminf(base, cur * 1.5f);
+                            t += cur;
+                        }
                         tile_trips++;
+                        replay_saturated(t, t_stop, base);
+                    }
+                    while (COUNT && t < t_stop) {                 // the instrumented launch counts every replayed step
                         if (COUNT) {
                             n_steps++; n_imp++;
                             if (gauss) {                          // the shader fetches the taps that lie inside [0,1]^3 (wgsl:58-66)
@@ -659,10 +669,24 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     ts[k] = tt;
-                    const V3 p = ray.o + ray.d * tt;              // wgsl:251
-                    offs[k] = nearest_offset(g, p);
                     cc = last_dense ? min_step : __builtin_fminf(base, cc * 1.5f);
                     tt += cc;
+                }
+                if constexpr (K % 2 == 0) {
+                    // two samples per instruction: o + d * t and the texel scale as packed f32 multiplies and adds (the same
+                    // IEEE operations per component, nothing fused)
+#pragma unroll
+                    for (int k = 0; k < K; k += 2) {
+                        const f32x2 tp = {ts[k], ts[k + 1]};
+                        const f32x2 ux = (ray.o.x + ray.d.x * tp) * g.fnx, uy = (ray.o.y + ray.d.y * tp) * g.fny, uz = (ray.o.z + ray.d.z * tp) * g.fnz;   // wgsl:251
+                        offs[k] = voxel_offset(g, clamp_texel(floor_to_int(ux.x), static_cast<int>(g.hix)), clamp_texel(floor_to_int(uy.x), static_cast<int>(g.hiy)),
+                                               clamp_texel(floor_to_int(uz.x), static_cast<int>(g.hiz)));
+                        offs[k + 1] = voxel_offset(g, clamp_texel(floor_to_int(ux.y), static_cast<int>(g.hix)), clamp_texel(floor_to_int(uy.y), static_cast<int>(g.hiy)),
+                                                   clamp_texel(floor_to_int(uz.y), static_cast<int>(g.hiz)));
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) offs[k] = nearest_offset(g, ray.o + ray.d * ts[k]);   // wgsl:251
                 }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
