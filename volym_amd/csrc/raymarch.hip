@@ -297,7 +297,8 @@ static int upload_volume(volym_ctx* c, uint8_t** dst, const uint8_t* src, uint32
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (*dst) { HIPCHK(c, hipFree(*dst)); *dst = nullptr; }
     uint8_t* staging = nullptr;
-    hipError_t e = hipMalloc(dst, nb);
+    hipError_t e = hipMalloc(dst, nb + 16);      // the trilinear fetch reads voxel pairs: one byte past the last voxel is touched
+    if (e == hipSuccess) e = hipMemset(*dst + nb, 0, 16);
     if (e == hipSuccess) e = hipMalloc(&staging, n);
     if (e != hipSuccess) { (void)hipFree(staging); return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(volume): ") + hipGetErrorString(e)); }
     e = hipMemcpy(VOLYM_BRICKED ? staging : *dst, src, n, hipMemcpyHostToDevice);

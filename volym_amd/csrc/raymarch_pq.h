@@ -741,6 +741,31 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 if (TRACE) tm_samp += PQ_TICK() - tm_mark;
                 continue;
             }
+            // straight look-ahead of all K samples side by side (uninstrumented launches; the instrumented one counts the
+            // probes the reference executes, sample by sample, below)
+            bool ahead_pre[K];
+            constexpr bool PRE_AHEAD = IMP && !COUNT && K > 1;
+            const bool pre_ahead = PRE_AHEAD && imp_rendering && !imp_coloring && !(flags & F_CONE);
+            if (PRE_AHEAD && pre_ahead) {
+                V3 starts[K];
+                bool need[K];
+                bool chain = active;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const bool dense_k = TABLE ? bs[k] >= fp.thr_byte : rhos[k] >= thr;
+                    starts[k] = ray.o + ray.d * ts[k];
+                    need[k] = chain && dense_k && ibs[k] < 255u;
+                    chain = chain && dense_k == last_dense;
+                }
+                bool any_need = false;
+#pragma unroll
+                for (int k = 0; k < K; ++k) any_need = any_need || need[k];
+                if (__ballot(any_need) != 0ull) ahead_straight_multi<K>(g, fp, starts, need, ray.d, ray.t_exit, ahead_pre);
+                else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) ahead_pre[k] = false;
+                }
+            }
             bool valid = active;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -775,8 +800,10 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                             use_alpha = true;                     // wgsl:279-281
                         } else {
                             if (imp_rendering) {                  // wgsl:283-295
-                                const bool ahead = (flags & F_CONE) ? ahead_cone<COUNT>(g, fp, pos, ray.d, ray.t_exit, n_imp)
-                                                                    : ahead_straight<COUNT>(g, fp, pos, ray.d, ray.t_exit, n_imp);
+                                bool ahead;
+                                if (PRE_AHEAD && pre_ahead) ahead = ahead_pre[k];
+                                else ahead = (flags & F_CONE) ? ahead_cone<COUNT>(g, fp, pos, ray.d, ray.t_exit, n_imp)
+                                                              : ahead_straight<COUNT>(g, fp, pos, ray.d, ray.t_exit, n_imp);
                                 suppressed = ibs[k] < 255u && ahead;
                             }
                             if (TABLE) alpha_step = s_tf_tab[bs[k]].w;
