@@ -57,7 +57,7 @@ struct FrameParams {
 };
 
 #ifndef VOLYM_DEV_SWITCHES
-#define VOLYM_DEV_SWITCHES 1
+#define VOLYM_DEV_SWITCHES 0     // make DEV=1 compiles the FrameParams::dev timing experiments in (scripts/ablate.py --dev)
 #endif
 
 enum : uint32_t {
