@@ -135,6 +135,43 @@ def test_teapot_config1(oracle, volym_lib):
                 _check(_render_gpu(ctx, cam, par, variant), ref, "teapot %s v%d" % (kw, variant))
 
 
+@pytest.mark.parametrize("filt", [0, 1], ids=["nearest", "linear"])
+def test_bricked_layout_matches_oracle(oracle, volym_lib, bonsai64, filt):
+    """The 4x4x4-brick layout the library picks for volumes beyond the Infinity Cache, forced here on a small volume
+    (dev option 112): same pixels, same reference-fetch counters, every kernel variant; dimensions that are not
+    multiples of 4 exercise the brick padding."""
+    raw, labels, dims, vol, imp = bonsai64
+    W, H = 96, 64
+    cam = oracle.benchmark_camera_uniforms(W / H)
+    lut = oracle.tf_default_lut()
+    combos = [f for i, f in enumerate(common.all_flag_combos()) if i % 5 == 0 or i == 31]
+    with _ctx(W, H) as ctx:
+        ctx.set_option(112, 1)
+        _setup_ctx(ctx, raw, labels, common.BONSAI_SEGMENTS, dims, filt)
+        for flags in combos:
+            par = oracle.make_parameters(density_threshold=0.15, importance_check_ahead_steps=6,
+                                         raymarching_step_size=0.01, **flags)
+            ref = oracle.render(vol, imp, dims, lut, cam, par, W, H, filter=filt)
+            for variant in VARIANTS:
+                _check(_render_gpu(ctx, cam, par, variant), ref, "bricked flags %s variant %d filter %d" % (common.flag_id(flags), variant, filt))
+    rng = np.random.default_rng(11)
+    for rdims in ((5, 3, 2), (17, 33, 9)):
+        n = rdims[0] * rdims[1] * rdims[2]
+        rvol = rng.integers(0, 256, n, dtype=np.uint8)
+        rimp = np.where(rng.integers(0, 4, n) == 0, 255, 0).astype(np.uint8)
+        W2, H2 = 37, 23
+        cam2 = oracle.benchmark_camera_uniforms(W2 / H2, 20.0, 10.0, 0.0)
+        with _ctx(W2, H2) as ctx:
+            ctx.set_option(112, 1)
+            ctx.set_volume(rvol, rdims, filt)
+            ctx.set_importances(rimp, rdims)
+            ctx.set_transfer_function(lut)
+            par = oracle.make_parameters(raymarching_step_size=0.02, use_importance_rendering=1, importance_check_ahead_steps=4)
+            ref = oracle.render(rvol, rimp, rdims, lut, cam2, par, W2, H2, filter=filt)
+            for variant in VARIANTS:
+                _check(_render_gpu(ctx, cam2, par, variant), ref, "bricked dims %s v%d filter %d" % (rdims, variant, filt))
+
+
 def test_ragged_viewport_and_tiny_volume(oracle, volym_lib):
     """Viewport not a multiple of 16 (guard wgsl:217-219), 1-voxel-thin and non-cubic volumes."""
     rng = np.random.default_rng(7)

@@ -73,6 +73,9 @@ struct volym_ctx {
     bool super_fill = true;
     uint32_t prio_tenths[3] = {3, 6, 10};   // cost / fair share (tenths) from which an item runs at issue priority 1, 2, 3 (first 0: off)
     bool dev_only_quarters = false;
+    bool bricked = false;          // layout of d_vol / d_imp (raymarch_device.h "Volume layout")
+    uint64_t brick_from_bytes = 192ull << 20;   // volumes above this many bytes are bricked
+    int layout_choice = -1;        // -1: by size, 0: linear, 1: bricked (dev option 112, before the uploads)
     size_t order_capacity = 0;     // entries d_order can hold
     uint32_t order_grid = 0;       // workgroups the cost-ordered list was dealt to (0: the geometric list, any grid)
     uint32_t dp_share_pct = 60;    // a quarter item's wave time as a percentage of the time its tile took as one item
@@ -228,7 +231,7 @@ int volym_set_option(volym_ctx* c, int key, int value)
         c->wgs_per_cu = static_cast<uint32_t>(value);
         return VOLYM_OK;
     case 102:   // undocumented tuning knob: speculation depth of variant 2 (1, 2 or 4)
-        if (value != 1 && value != 2 && value != 4) return fail(c, VOLYM_E_INVALID, "speculation depth: 1, 2 or 4");
+        if (value != 4) return fail(c, VOLYM_E_INVALID, "speculation depth: 4 (the shallower variants were dropped)");
         c->kspec = value;
         return VOLYM_OK;
     case 105:   // undocumented: measured cost from which tiles are marched depth-parallel (0 = never)
@@ -245,6 +248,10 @@ int volym_set_option(volym_ctx* c, int key, int value)
         return VOLYM_OK;
     case 110:   // undocumented experiment: FrameParams::dev
         c->fp.dev = static_cast<uint32_t>(value);
+        return VOLYM_OK;
+    case 112:   // undocumented: volume layout, -1 by size / 0 linear / 1 bricked; set before volym_set_volume / volym_set_importances
+        if (value < -1 || value > 1) return fail(c, VOLYM_E_INVALID, "layout: -1, 0 or 1");
+        c->layout_choice = value;
         return VOLYM_OK;
     case 111:   // undocumented: balancing estimates, dp_share_pct + 1000 * fill_cost
         c->dp_share_pct = static_cast<uint32_t>(value % 1000);
@@ -286,11 +293,14 @@ int volym_set_shard(volym_ctx* c, uint32_t rank, uint32_t world)
     return VOLYM_OK;
 }
 
+static bool want_bricked(const volym_ctx* c, uint32_t nx, uint32_t ny, uint32_t nz);
+
 static int upload_volume(volym_ctx* c, uint8_t** dst, const uint8_t* src, uint32_t nx, uint32_t ny, uint32_t nz)
 {
+    const bool bricked = want_bricked(c, nx, ny, nz);
     if (!src || nx == 0 || ny == 0 || nz == 0) return fail(c, VOLYM_E_INVALID, "volume: NULL data or zero dimension");
     const uint64_t n = static_cast<uint64_t>(nx) * ny * nz;
-    const uint64_t nb = VOLYM_BRICKED ? static_cast<uint64_t>(brick_count(nx)) * brick_count(ny) * brick_count(nz) * 64u : n;
+    const uint64_t nb = bricked ? static_cast<uint64_t>(brick_count(nx)) * brick_count(ny) * brick_count(nz) * 64u : n;
     if (nx > 4096 || ny > 4096 || nz > 4096 || nb > 0xffffffffull)
         return fail(c, VOLYM_E_INVALID, "volume: each dimension <= 4096 and the brick-padded size < 2^32");
     HIPCHK(c, hipSetDevice(c->device));
@@ -299,10 +309,10 @@ static int upload_volume(volym_ctx* c, uint8_t** dst, const uint8_t* src, uint32
     uint8_t* staging = nullptr;
     hipError_t e = hipMalloc(dst, nb + 16);      // the trilinear fetch reads voxel pairs: one byte past the last voxel is touched
     if (e == hipSuccess) e = hipMemset(*dst + nb, 0, 16);
-    if (e == hipSuccess) e = hipMalloc(&staging, n);
+    if (e == hipSuccess && bricked) e = hipMalloc(&staging, n);
     if (e != hipSuccess) { (void)hipFree(staging); return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(volume): ") + hipGetErrorString(e)); }
-    e = hipMemcpy(VOLYM_BRICKED ? staging : *dst, src, n, hipMemcpyHostToDevice);
-    if (e == hipSuccess && VOLYM_BRICKED) {
+    e = hipMemcpy(bricked ? staging : *dst, src, n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && bricked) {
         hipLaunchKernelGGL(volym_rebrick_kernel, dim3(static_cast<uint32_t>((nb + 255u) / 256u)), dim3(256), 0, c->stream, staging, *dst, nx, ny, nz);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -310,6 +320,14 @@ static int upload_volume(volym_ctx* c, uint8_t** dst, const uint8_t* src, uint32
     (void)hipFree(staging);
     if (e != hipSuccess) return fail(c, VOLYM_E_HIP, std::string("volume upload: ") + hipGetErrorString(e));
     return VOLYM_OK;
+}
+
+// Bricks pay when the volume no longer fits the 256 MB Infinity Cache (see raymarch_device.h); volume and importances of
+// the same dimensions get the same answer.
+static bool want_bricked(const volym_ctx* c, uint32_t nx, uint32_t ny, uint32_t nz)
+{
+    if (c->layout_choice >= 0) return c->layout_choice == 1;
+    return static_cast<uint64_t>(nx) * ny * nz > c->brick_from_bytes;
 }
 
 int volym_set_volume(volym_ctx* c, const uint8_t* voxels, uint32_t nx, uint32_t ny, uint32_t nz, int filter)
@@ -320,6 +338,7 @@ int volym_set_volume(volym_ctx* c, const uint8_t* voxels, uint32_t nx, uint32_t 
     int rc = upload_volume(c, &c->d_vol, voxels, nx, ny, nz);
     if (rc != VOLYM_OK) { c->have_vol = false; return rc; }
     c->nx = nx; c->ny = ny; c->nz = nz; c->filter = filter;
+    c->bricked = want_bricked(c, nx, ny, nz);
     c->have_vol = true;
     c->mc_dirty = true;
     invalidate_costs(c);
@@ -654,7 +673,7 @@ static int ensure_frame_resources(volym_ctx* c)
         hipError_t e = hipMalloc(&c->d_mc, cells);
         if (e == hipSuccess) e = hipMalloc(&c->d_df, (cells / 2u + 15u) / 16u * 16u);
         if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(macro cells): ") + hipGetErrorString(e));
-        hipLaunchKernelGGL(volym_macrocell_kernel, dim3(cells), dim3(256), 0, c->stream, c->d_vol, c->d_mc, c->nx, c->ny, c->nz, c->mc_n);
+        hipLaunchKernelGGL(volym_macrocell_kernel, dim3(cells), dim3(256), 0, c->stream, c->d_vol, c->d_mc, c->nx, c->ny, c->nz, c->mc_n, c->bricked ? 1u : 0u);
         HIPCHK(c, hipGetLastError());
         c->mc_dirty = false;
         c->mc_built_n = c->mc_n;
@@ -784,27 +803,30 @@ static int launch_march(volym_ctx* c)
         const uint32_t want = (c->n_items + PQ_WAVES - 1) / PQ_WAVES;
         const uint32_t pgrid = c->order_grid ? c->order_grid : std::max(1u, std::min(want, static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu));
         const bool table = !(fp.flags & (F_LINEAR | F_GAUSSIAN));
-#define VOLYM_PQ_LAUNCH(T, KS)                                                                                                   \
-    hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT, TRACE, KS>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,  \
+#define VOLYM_PQ_LAUNCH(T, KS, I, B)                                                                                             \
+    hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT && I, TRACE, KS, I, B>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,  \
                        c->d_imp, c->d_tables, c->d_df, c->d_order, c->n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
-        const bool no_imp = !(fp.flags & (F_IMP_COLORING | F_IMP_RENDERING)) && (fp.flags & F_OPACITY);
-        if (table && c->kspec == 4 && no_imp && !COUNT)
-            hipLaunchKernelGGL((volym_raymarch_pq_kernel<true, false, TRACE, 4, false>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,
-                               c->d_imp, c->d_tables, c->d_df, c->d_order, c->n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp);
-        else if (table && c->kspec == 4) VOLYM_PQ_LAUNCH(true, 4);
-        else if (table && c->kspec == 2) VOLYM_PQ_LAUNCH(true, 2);
-        else if (table) VOLYM_PQ_LAUNCH(true, 1);
-        else VOLYM_PQ_LAUNCH(false, 1);
+        // IMP = false: opacity on and no importance mode (the common case); the instrumented launch always takes the general form
+        const bool no_imp = !COUNT && !(fp.flags & (F_IMP_COLORING | F_IMP_RENDERING)) && (fp.flags & F_OPACITY);
+        if (c->bricked) {
+            if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, true);
+            else if (table) VOLYM_PQ_LAUNCH(true, 4, true, true);
+            else VOLYM_PQ_LAUNCH(false, 1, true, true);
+        } else {
+            if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, false);
+            else if (table) VOLYM_PQ_LAUNCH(true, 4, true, false);
+            else VOLYM_PQ_LAUNCH(false, 1, true, false);
+        }
 #undef VOLYM_PQ_LAUNCH
         HIPCHK(c, hipGetLastError());
         return VOLYM_OK;
     }
-    if (c->kernel_variant >= 1)
-        hipLaunchKernelGGL((volym_raymarch_kernel<1, COUNT, TRACE>), dim3(grid), dim3(256), 0, c->stream, c->d_vol, c->d_imp, c->d_tables,
-                           c->d_df, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp);
-    else
-        hipLaunchKernelGGL((volym_raymarch_kernel<0, COUNT, TRACE>), dim3(grid), dim3(256), 0, c->stream, c->d_vol, c->d_imp, c->d_tables,
-                           c->d_df, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp);
+#define VOLYM_DIRECT_LAUNCH(V, B)                                                                                                \
+    hipLaunchKernelGGL((volym_raymarch_kernel<V, COUNT, TRACE, B>), dim3(grid), dim3(256), 0, c->stream, c->d_vol, c->d_imp, c->d_tables, \
+                       c->d_df, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
+    if (c->kernel_variant >= 1) { if (c->bricked) VOLYM_DIRECT_LAUNCH(1, true); else VOLYM_DIRECT_LAUNCH(1, false); }
+    else { if (c->bricked) VOLYM_DIRECT_LAUNCH(0, true); else VOLYM_DIRECT_LAUNCH(0, false); }
+#undef VOLYM_DIRECT_LAUNCH
     HIPCHK(c, hipGetLastError());
     return VOLYM_OK;
 }

@@ -103,41 +103,41 @@ __device__ __forceinline__ float dot_fast(V3 a, V3 b)
     return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
 }
 
-// Volume layout in HBM.  VOLYM_BRICKED = 1 stores 4x4x4 bricks of 64 bytes (brick index x fastest, then y,
-// then z; inside a brick x fastest).  Measured on the bench workload (round 1): no gain -- the march is
-// bound by instruction issue and dependent latency, not by L2 misses -- and ~10 extra integer
-// instructions per address, so the default is the linear layout x + nx*(y + ny*z).
-#ifndef VOLYM_BRICKED
-#define VOLYM_BRICKED 0
-#endif
+// Volume layout in HBM, chosen per volume on the host (volym_set_volume):
+//   linear   x + nx*(y + ny*z): two 24-bit multiply-adds per address.  Best while the volume is cache-resident (a
+//            256^3 march is bound by instruction issue, not by L2 misses: bricks cost ~9 more integer instructions per
+//            address and gained nothing, 38.1 vs 36.6 us);
+//   bricked  4x4x4 bricks of 64 bytes (brick index x fastest, then y, then z; inside a brick x fastest): the 8x8-pixel
+//            footprint of a wave and the +-y/+-z gradient taps fall into the same 64-byte sectors.  At 1024^3 (1 GiB,
+//            beyond the 256 MB Infinity Cache) the march is bound by sector fetches: 238 -> 121 us at 4K.
 __host__ __device__ inline uint32_t brick_count(uint32_t n) { return (n + 3u) >> 2; }
 
-struct Grid {
+template <bool BRICK>
+struct GridT {
+    static constexpr bool bricked = BRICK;
     const uint8_t* __restrict__ vol;
     const uint8_t* __restrict__ imp;
     int nx, ny, nz;
-    uint32_t bx, bxy;         // bricks per row, bricks per slab
+    uint32_t bx, bxy;         // bricks per row, bricks per slab (bricked) or nx, nx*ny (linear)
     float fnx, fny, fnz;      // (float)n
     float hix, hiy, hiz;      // (float)(n - 1)
 };
+typedef GridT<false> Grid;
 
-// bx, bxy: bricks per row / per slab (bricked) or nx, nx*ny (linear)
-__host__ __device__ inline uint32_t bricked_offset(uint32_t bx, uint32_t bxy, uint32_t ix, uint32_t iy, uint32_t iz)
+__host__ __device__ inline uint32_t layout_offset(bool bricked, uint32_t bx, uint32_t bxy, uint32_t ix, uint32_t iy, uint32_t iz)
 {
-#if VOLYM_BRICKED
-    return (((iz >> 2) * bxy + (iy >> 2) * bx + (ix >> 2)) << 6) | ((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u);
-#else
+    if (bricked) return (((iz >> 2) * bxy + (iy >> 2) * bx + (ix >> 2)) << 6) | ((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u);
     return ix + bx * iy + bxy * iz;
-#endif
 }
-__host__ __device__ inline uint32_t layout_bx(uint32_t nx) { return VOLYM_BRICKED ? brick_count(nx) : nx; }
-__host__ __device__ inline uint32_t layout_bxy(uint32_t nx, uint32_t ny) { return VOLYM_BRICKED ? brick_count(nx) * brick_count(ny) : nx * ny; }
+__host__ __device__ inline uint32_t layout_bx(bool bricked, uint32_t nx) { return bricked ? brick_count(nx) : nx; }
+__host__ __device__ inline uint32_t layout_bxy(bool bricked, uint32_t nx, uint32_t ny) { return bricked ? brick_count(nx) * brick_count(ny) : nx * ny; }
 
-__device__ __forceinline__ void grid_init(Grid& g, const uint8_t* vol, const uint8_t* imp, uint32_t nx, uint32_t ny, uint32_t nz)
+template <class G>
+__device__ __forceinline__ void grid_init(G& g, const uint8_t* vol, const uint8_t* imp, uint32_t nx, uint32_t ny, uint32_t nz)
 {
     g.vol = vol; g.imp = imp;
     g.nx = static_cast<int>(nx); g.ny = static_cast<int>(ny); g.nz = static_cast<int>(nz);
-    g.bx = layout_bx(nx); g.bxy = layout_bxy(nx, ny);
+    g.bx = layout_bx(G::bricked, nx); g.bxy = layout_bxy(G::bricked, nx, ny);
     g.fnx = static_cast<float>(nx); g.fny = static_cast<float>(ny); g.fnz = static_cast<float>(nz);
     g.hix = static_cast<float>(nx - 1u); g.hiy = static_cast<float>(ny - 1u); g.hiz = static_cast<float>(nz - 1u);
 }
@@ -175,17 +175,21 @@ __device__ __forceinline__ int texel_nearest(float u, float fn, float hi)
     return clamp_texel(floor_to_int(u * fn), static_cast<int>(hi));
 }
 
-__device__ __forceinline__ uint32_t voxel_offset(const Grid& g, int ix, int iy, int iz)
+template <class G>
+__device__ __forceinline__ uint32_t voxel_offset(const G& g, int ix, int iy, int iz)
 {
-#if VOLYM_BRICKED
-    return bricked_offset(g.bx, g.bxy, static_cast<uint32_t>(ix), static_cast<uint32_t>(iy), static_cast<uint32_t>(iz));
-#else
-    // x + nx*(y + ny*z) with two full-rate 24-bit multiplies: ny*z + y <= 4096*4095 + 4095 < 2^24 for every allowed size
-    return mad_u24(mad_u24(static_cast<uint32_t>(iz), static_cast<uint32_t>(g.ny), static_cast<uint32_t>(iy)), static_cast<uint32_t>(g.nx), static_cast<uint32_t>(ix));
-#endif
+    if constexpr (G::bricked) {
+        const uint32_t x = static_cast<uint32_t>(ix), y = static_cast<uint32_t>(iy), z = static_cast<uint32_t>(iz);
+        const uint32_t brick = mad_u24(z >> 2, g.bxy, mad_u24(y >> 2, g.bx, x >> 2));      // < 2^24 bricks: volumes below 2^30 voxels
+        return (brick << 6) | ((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u);
+    } else {
+        // x + nx*(y + ny*z) with two full-rate 24-bit multiplies: ny*z + y <= 4096*4095 + 4095 < 2^24 for every allowed size
+        return mad_u24(mad_u24(static_cast<uint32_t>(iz), static_cast<uint32_t>(g.ny), static_cast<uint32_t>(iy)), static_cast<uint32_t>(g.nx), static_cast<uint32_t>(ix));
+    }
 }
 
-__device__ __forceinline__ uint32_t nearest_offset(const Grid& g, V3 p)
+template <class G>
+__device__ __forceinline__ uint32_t nearest_offset(const G& g, V3 p)
 {
     return voxel_offset(g, texel_nearest(p.x, g.fnx, g.hix), texel_nearest(p.y, g.fny, g.hiy),
                         texel_nearest(p.z, g.fnz, g.hiz));
@@ -210,33 +214,35 @@ __device__ __forceinline__ uint32_t load_voxel_pair(const uint8_t* p)
     return reinterpret_cast<const UnalignedU16*>(p)->v;
 }
 
-__device__ __forceinline__ float fetch_linear(const Grid& g, const float* __restrict__ s_rho, V3 p)
+template <class G>
+__device__ __forceinline__ float fetch_linear(const G& g, const float* __restrict__ s_rho, V3 p)
 {
     int x0, x1, y0, y1, z0, z1;
     float fx, fy, fz;
     texel_linear(p.x, g.fnx, g.nx, x0, x1, fx);
     texel_linear(p.y, g.fny, g.ny, y0, y1, fy);
     texel_linear(p.z, g.fnz, g.nz, z0, z1, fz);
-#if VOLYM_BRICKED
-    const float t000 = s_rho[g.vol[voxel_offset(g, x0, y0, z0)]];
-    const float t100 = s_rho[g.vol[voxel_offset(g, x1, y0, z0)]];
-    const float t010 = s_rho[g.vol[voxel_offset(g, x0, y1, z0)]];
-    const float t110 = s_rho[g.vol[voxel_offset(g, x1, y1, z0)]];
-    const float t001 = s_rho[g.vol[voxel_offset(g, x0, y0, z1)]];
-    const float t101 = s_rho[g.vol[voxel_offset(g, x1, y0, z1)]];
-    const float t011 = s_rho[g.vol[voxel_offset(g, x0, y1, z1)]];
-    const float t111 = s_rho[g.vol[voxel_offset(g, x1, y1, z1)]];
-#else
+    float t000, t100, t010, t110, t001, t101, t011, t111;
+    if constexpr (G::bricked) {
+    t000 = s_rho[g.vol[voxel_offset(g, x0, y0, z0)]];
+    t100 = s_rho[g.vol[voxel_offset(g, x1, y0, z0)]];
+    t010 = s_rho[g.vol[voxel_offset(g, x0, y1, z0)]];
+    t110 = s_rho[g.vol[voxel_offset(g, x1, y1, z0)]];
+    t001 = s_rho[g.vol[voxel_offset(g, x0, y0, z1)]];
+    t101 = s_rho[g.vol[voxel_offset(g, x1, y0, z1)]];
+    t011 = s_rho[g.vol[voxel_offset(g, x0, y1, z1)]];
+    t111 = s_rho[g.vol[voxel_offset(g, x1, y1, z1)]];
+    } else {
     // x1 is x0 + 1, or x0 itself at either edge of the row: the two texels of a row are one (unaligned) 16-bit gather
     // instead of two byte gathers.  The volume is allocated with 16 bytes to spare.
     const bool same_x = x1 == x0;
     const uint32_t p00 = load_voxel_pair(g.vol + voxel_offset(g, x0, y0, z0)), p10 = load_voxel_pair(g.vol + voxel_offset(g, x0, y1, z0));
     const uint32_t p01 = load_voxel_pair(g.vol + voxel_offset(g, x0, y0, z1)), p11 = load_voxel_pair(g.vol + voxel_offset(g, x0, y1, z1));
-    const float t000 = s_rho[p00 & 255u], t100 = s_rho[same_x ? (p00 & 255u) : (p00 >> 8)];
-    const float t010 = s_rho[p10 & 255u], t110 = s_rho[same_x ? (p10 & 255u) : (p10 >> 8)];
-    const float t001 = s_rho[p01 & 255u], t101 = s_rho[same_x ? (p01 & 255u) : (p01 >> 8)];
-    const float t011 = s_rho[p11 & 255u], t111 = s_rho[same_x ? (p11 & 255u) : (p11 >> 8)];
-#endif
+    t000 = s_rho[p00 & 255u], t100 = s_rho[same_x ? (p00 & 255u) : (p00 >> 8)];
+    t010 = s_rho[p10 & 255u], t110 = s_rho[same_x ? (p10 & 255u) : (p10 >> 8)];
+    t001 = s_rho[p01 & 255u], t101 = s_rho[same_x ? (p01 & 255u) : (p01 >> 8)];
+    t011 = s_rho[p11 & 255u], t111 = s_rho[same_x ? (p11 & 255u) : (p11 >> 8)];
+    }
     const float c00 = t000 * (1.0f - fx) + t100 * fx;
     const float c10 = t010 * (1.0f - fx) + t110 * fx;
     const float c01 = t001 * (1.0f - fx) + t101 * fx;
@@ -246,7 +252,8 @@ __device__ __forceinline__ float fetch_linear(const Grid& g, const float* __rest
     return c0 * (1.0f - fz) + c1 * fz;
 }
 
-__device__ __forceinline__ float sample_density(const Grid& g, const float* __restrict__ s_rho, bool linear, V3 p)
+template <class G>
+__device__ __forceinline__ float sample_density(const G& g, const float* __restrict__ s_rho, bool linear, V3 p)
 {
     if (linear) return fetch_linear(g, s_rho, p);
     return s_rho[g.vol[nearest_offset(g, p)]];
@@ -258,8 +265,8 @@ __device__ __forceinline__ bool outside01(V3 p)
 }
 
 // wgsl:52-75, 5 taps along the ray, out-of-volume taps skipped  (EXACT)
-template <bool COUNT>
-__device__ __forceinline__ float sample_density_smoothed(const Grid& g, const float* __restrict__ s_rho,
+template <bool COUNT, class G>
+__device__ __forceinline__ float sample_density_smoothed(const G& g, const float* __restrict__ s_rho,
                                                          bool linear, const FrameParams& fp, V3 pos, V3 dir,
                                                          uint32_t& n_vol)
 {
@@ -296,8 +303,8 @@ __device__ __forceinline__ float4 sample_tf(const float4* __restrict__ s_lut, ui
 #define VOLYM_PROBE_BATCH 4
 
 // wgsl:141-160  (EXACT)
-template <bool COUNT>
-__device__ __forceinline__ bool ahead_straight(const Grid& g, const FrameParams& fp, V3 cur, V3 dir, float t_exit,
+template <bool COUNT, class G>
+__device__ __forceinline__ bool ahead_straight(const G& g, const FrameParams& fp, V3 cur, V3 dir, float t_exit,
                                                uint32_t& n_imp)
 {
     V3 pos = cur;
@@ -325,8 +332,8 @@ __device__ __forceinline__ bool ahead_straight(const Grid& g, const FrameParams&
 // depend on its position only, not on the opacity accumulated before it, so the K chains of dependent importance fetches
 // run side by side instead of one after the other.  Same positions, same f32 operations per chain as ahead_straight; the
 // early exit of a chain only ever saved fetches, never changed the answer.
-template <int K>
-__device__ __forceinline__ void ahead_straight_multi(const Grid& g, const FrameParams& fp, const V3 (&start)[K], const bool (&need)[K], V3 dir,
+template <int K, class G>
+__device__ __forceinline__ void ahead_straight_multi(const G& g, const FrameParams& fp, const V3 (&start)[K], const bool (&need)[K], V3 dir,
                                                      float t_exit, bool (&found)[K])
 {
     const int n = static_cast<int>(fp.ahead_steps);
@@ -363,8 +370,8 @@ __device__ __forceinline__ void ahead_straight_multi(const Grid& g, const FrameP
 }
 
 // wgsl:94-139  (EXACT)
-template <bool COUNT>
-__device__ __forceinline__ bool ahead_cone(const Grid& g, const FrameParams& fp, V3 cur, V3 dir, float t_exit,
+template <bool COUNT, class G>
+__device__ __forceinline__ bool ahead_cone(const G& g, const FrameParams& fp, V3 cur, V3 dir, float t_exit,
                                            uint32_t& n_imp)
 {
     const int n = static_cast<int>(fp.ahead_steps);

@@ -41,8 +41,8 @@ struct MarchCtx {
     bool linear, table_mode;
 };
 
-template <bool COUNT>
-__device__ __forceinline__ int dense_sample(const MarchCtx& m, const Grid& g, const FrameParams& fp, const Ray& ray, V3 pos,
+template <bool COUNT, class G>
+__device__ __forceinline__ int dense_sample(const MarchCtx& m, const G& g, const FrameParams& fp, const Ray& ray, V3 pos,
                                             int ix, int iy, int iz, uint32_t off, uint32_t b, float rho, float& t, float cur,
                                             V3& acc, float& acc_a, uint32_t& n_vol, uint32_t& n_imp)
 {
@@ -111,7 +111,7 @@ __device__ __forceinline__ int dense_sample(const MarchCtx& m, const Grid& g, co
 // LDS bytes of the packed 4-bit distance field for the largest macro grid (32^3 cells)
 #define VOLYM_DF_LDS_BYTES 16384
 
-template <int VARIANT, bool COUNT, bool TRACE>
+template <int VARIANT, bool COUNT, bool TRACE, bool BRICK = false>
 __global__ __launch_bounds__(256) void volym_raymarch_kernel(
     const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
     const uint8_t* __restrict__ df4, uint32_t* __restrict__ out_shard, uint32_t* __restrict__ out_raster,
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
     const uint32_t gx = tx * 16u + px, gy = ty * 16u + py;
     const bool in_frame = gx < fp.W && gy < fp.H;   // wgsl:217-219
 
-    Grid g;
+    GridT<BRICK> g;
     grid_init(g, vol, imp, fp.nx, fp.ny, fp.nz);
 
     uint32_t n_vol = 0, n_imp = 0, n_steps = 0, n_dense = 0, n_hit = 0;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(1024) void volym_distance_field_kernel(const uint8_
 // per-cell maxima of the density volume: cell (cx,cy,cz) of the mc_n^3 grid covers the voxels a
 // nearest-filter sample with pos in [c/mc_n, (c+1)/mc_n) can select, i.e. floor(pos*n) for those pos.
 __global__ __launch_bounds__(256) void volym_macrocell_kernel(const uint8_t* __restrict__ vol, uint8_t* __restrict__ mc_max,
-                                                              uint32_t nx, uint32_t ny, uint32_t nz, uint32_t mc_n)
+                                                              uint32_t nx, uint32_t ny, uint32_t nz, uint32_t mc_n, uint32_t bricked)
 {
     const uint32_t cell = blockIdx.x;
     const uint32_t cx = cell % mc_n, cy = (cell / mc_n) % mc_n, cz = cell / (mc_n * mc_n);
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void volym_macrocell_kernel(const uint8_t* __r
     uint32_t m = 0;
     for (uint32_t i = threadIdx.x; i < total; i += 256u) {
         const uint32_t x = x0 + i % wx, y = y0 + (i / wx) % wy, z = z0 + i / (wx * wy);
-        const uint32_t v = vol[bricked_offset(layout_bx(nx), layout_bxy(nx, ny), x, y, z)];
+        const uint32_t v = vol[layout_offset(bricked != 0u, layout_bx(bricked != 0u, nx), layout_bxy(bricked != 0u, nx, ny), x, y, z)];
         m = v > m ? v : m;
     }
     for (int s = 32; s > 0; s >>= 1) { const uint32_t o = __shfl_xor(m, s, 64); m = o > m ? o : m; }

@@ -105,7 +105,7 @@ __device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, const H
     if (out_obj) return in_cube ? TILE_FILL_EMPTY : TILE_HIT_TEST;
     return TILE_MARCH;
 }
-template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true>
+template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true, bool BRICK = false>
 __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
     const uint8_t* __restrict__ df4, const uint32_t* __restrict__ order, uint32_t n_items, uint16_t* __restrict__ cost,
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    Grid g;
+    GridT<BRICK> g;
     grid_init(g, vol, imp, fp.nx, fp.ny, fp.nz);
 
     float4* const q4 = s_q[wave];
