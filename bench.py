@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--volume", type=int, default=256)
     ap.add_argument("--step", type=float, default=0.01)
+    ap.add_argument("--layout", type=int, default=-1, help="volume layout: -1 by size (bricks beyond 64 MiB), 0 linear, 1 4x4x4 bricks")
     ap.add_argument("--kernel", type=int, default=2,
                     help="0 direct (BASELINE configs[1]), 1 macro-cell, 2 persistent + LDS staging + shading queue (configs[2], default)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the driver's runs) or gloo (rehearsal on one device)")
@@ -152,6 +153,8 @@ def main():
 
     ctx = demo.GpuContext(W, H, local_rank)
     ctx.set_option(_lib.OPT_KERNEL, args.kernel)
+    if args.layout >= 0:
+        ctx.set_option(112, args.layout)
     if args.xcd_bands >= 0:
         ctx.set_option(_lib.OPT_XCD_BANDS, args.xcd_bands)
     ctx.set_shard(rank, world)
@@ -233,6 +236,8 @@ def main():
             assembled = frame.clone()
             solo = demo.GpuContext(W, H, local_rank)
             solo.set_option(_lib.OPT_KERNEL, args.kernel)
+            if args.layout >= 0:
+                solo.set_option(112, args.layout)
             solo.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
             solo.set_importances(importances, dims)
             solo.set_transfer_function(lut)

@@ -108,8 +108,9 @@ __device__ __forceinline__ float dot_fast(V3 a, V3 b)
 //            256^3 march is bound by instruction issue, not by L2 misses: bricks cost ~9 more integer instructions per
 //            address and gained nothing, 38.1 vs 36.6 us);
 //   bricked  4x4x4 bricks of 64 bytes (brick index x fastest, then y, then z; inside a brick x fastest): the 8x8-pixel
-//            footprint of a wave and the +-y/+-z gradient taps fall into the same 64-byte sectors.  At 1024^3 (1 GiB,
-//            beyond the 256 MB Infinity Cache) the march is bound by sector fetches: 238 -> 121 us at 4K.
+//            footprint of a wave and the +-y/+-z gradient taps fall into the same 64-byte sectors.  Beyond the L2s the
+//            march is bound by sector fetches: 512^3 at 1080p 54.3 -> 39.7 us, 1024^3 at 4K 238 -> 121 us (and with
+//            the importance volume beside it, BASELINE configs[4] on one GPU, 584 -> 284 us).
 __host__ __device__ inline uint32_t brick_count(uint32_t n) { return (n + 3u) >> 2; }
 
 template <bool BRICK>
