@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvolym_hip.so")
+LIB_PATH = os.environ.get("VOLYM_HIP_LIB") or os.path.join(_HERE, "libvolym_hip.so")   # the override is for A/B builds during development
 
 OK, E_INVALID, E_HIP, E_NO_DEVICE, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5
 FILTER_NEAREST, FILTER_LINEAR = 0, 1

@@ -370,6 +370,68 @@ __device__ __forceinline__ void ahead_straight_multi(const G& g, const FramePara
     }
 }
 
+// The cone look-ahead of one sample per lane, spread over the wave (uninstrumented launches): lane 8c + d of a round
+// walks cone direction d of the c-th sample that needs a look-ahead, so the 8 chains of a sample run side by side and the
+// lanes whose sample needs none work for the others.  Same positions and f32 operations per direction as ahead_cone; a
+// direction's early exit only ever saved fetches.  `cone_xo`/`cone_yo`: fp.cone_cos/sin[lane & 7] * 0.2, selected once per
+// kernel.  Every lane of the wave must call this (ballots and cross-lane reads inside).
+template <class G>
+__device__ __forceinline__ bool ahead_cone_wave(const G& g, const FrameParams& fp, bool need, V3 start, V3 dir, float t_exit, uint32_t lane,
+                                                float cone_xo, float cone_yo)
+{
+    const unsigned long long mask = __ballot(need);
+    if (mask == 0ull) return false;
+    const int n = static_cast<int>(fp.ahead_steps);
+    const uint32_t n_cand = static_cast<uint32_t>(__popcll(mask));
+    const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+    const float my_step = (t_exit - length_exact(start)) / static_cast<float>(n);
+    bool found = false;
+    unsigned long long rest = mask;
+    for (uint32_t r = 0; r * 8u < n_cand; ++r) {
+        // the lanes of the next (up to) 8 samples, 6 bits each (wave-uniform)
+        unsigned long long owners = 0ull;
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; ++i) {
+            if (rest != 0ull) {
+                owners |= static_cast<unsigned long long>(__builtin_ctzll(rest)) << (6u * i);
+                rest &= rest - 1ull;
+            }
+        }
+        const uint32_t c = lane >> 3;
+        const bool job = r * 8u + c < n_cand;
+        const int owner = static_cast<int>((owners >> (6u * c)) & 63ull);
+        const V3 p0 = v3(__shfl(start.x, owner, 64), __shfl(start.y, owner, 64), __shfl(start.z, owner, 64));
+        const V3 d0 = v3(__shfl(dir.x, owner, 64), __shfl(dir.y, owner, 64), __shfl(dir.z, owner, 64));
+        const float step = __shfl(my_step, owner, 64);
+        const V3 right = normalize_exact(cross(d0, v3(0.0f, 1.0f, 0.0f)));       // wgsl:99-113, as ahead_cone
+        const V3 new_up = cross(d0, right);
+        const V3 sd = normalize_exact((d0 + right * cone_xo) + new_up * cone_yo);
+        V3 pos = p0;
+        bool left = !job, hit = false;                                             // left: this direction has left [0,1]^3 (wgsl:122-124)
+        for (int i = 0; i < n; i += VOLYM_PROBE_BATCH) {
+            uint32_t ib[VOLYM_PROBE_BATCH];
+            bool out[VOLYM_PROBE_BATCH];
+#pragma unroll
+            for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
+                pos = pos + sd * step;
+                out[j] = outside01(pos);
+                ib[j] = g.imp[nearest_offset(g, pos)];                            // clamped offset: safe wherever pos is
+            }
+#pragma unroll
+            for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
+                if (!left && !hit && i + j < n) {
+                    if (out[j]) left = true;
+                    else if (ib[j] >= 128u) hit = true;                           // i/255 >= 0.5  <=>  i >= 128
+                }
+            }
+            if (__ballot(!left && !hit) == 0ull) break;
+        }
+        const unsigned long long hits = __ballot(hit);
+        if (need && (my_rank >> 3) == r) found = ((hits >> (8u * (my_rank & 7u))) & 0xffull) != 0ull;
+    }
+    return found;
+}
+
 // wgsl:94-139  (EXACT)
 template <bool COUNT, class G>
 __device__ __forceinline__ bool ahead_cone(const G& g, const FrameParams& fp, V3 cur, V3 dir, float t_exit,

@@ -70,20 +70,10 @@ enum : uint32_t { TILE_MARCH = 0, TILE_HIT_TEST = 1, TILE_FILL_EMPTY = 2, TILE_F
 struct HullEdge { float a, b, c; bool valid; };
 __device__ __forceinline__ HullEdge load_hull_edge(const FrameParams& fp, uint32_t lane)
 {
-    // 16 uniform reads and selects: indexing the by-value argument struct with the lane would make the compiler keep
-    // a copy of it in scratch memory
-    const uint32_t mine = lane >> 2;
-    float a = 0.0f, b = 0.0f, c = 0.0f, v = 0.0f;
-#pragma unroll
-    for (uint32_t i = 0; i < 16u; ++i) {
-        const bool m = mine == i;
-        a = m ? fp.hull[i >> 3][i & 7u][0] : a;
-        b = m ? fp.hull[i >> 3][i & 7u][1] : b;
-        c = m ? fp.hull[i >> 3][i & 7u][2] : c;
-        v = m ? fp.hull[i >> 3][i & 7u][3] : v;
-    }
+    // one gather from the kernel-argument segment per kernel
+    const uint32_t h = lane >> 5, e = (lane >> 2) & 7u;
     HullEdge r;
-    r.a = a; r.b = b; r.c = c; r.valid = v > 0.5f;
+    r.a = fp.hull[h][e][0]; r.b = fp.hull[h][e][1]; r.c = fp.hull[h][e][2]; r.valid = fp.hull[h][e][3] > 0.5f;
     return r;
 }
 __device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, const HullEdge& edge, uint32_t lane, float x0, float y0, float extent = 7.0f)
@@ -196,6 +186,8 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     };
     const bool culling = !COUNT && fp.cull != 0u;
     const HullEdge hull_edge = load_hull_edge(fp, lane);
+    // this lane's cone direction (lane & 7) for the wave-wide cone look-ahead, computed where it is used (two gathers
+    // from the kernel-argument segment and two multiplies per call: nothing kept live across the march)
     for (uint32_t ticket = grab(); ticket < n_mine; ticket = grab()) {
       {
         // item = local_tile*4 + sub (an 8x8 wave tile, one lane per ray), or, for tiles the cost feedback
@@ -745,8 +737,18 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             // probes the reference executes, sample by sample, below)
             bool ahead_pre[K];
             constexpr bool PRE_AHEAD = IMP && !COUNT && K > 1;
-            const bool pre_ahead = PRE_AHEAD && imp_rendering && !imp_coloring && !(flags & F_CONE);
-            if (PRE_AHEAD && pre_ahead) {
+            const bool pre_ahead = PRE_AHEAD && imp_rendering && !imp_coloring;
+            if (PRE_AHEAD && pre_ahead && (flags & F_CONE)) {
+                // cone look-ahead: one phase per speculative sample, the 8 directions of 8 samples at a time on the 64 lanes
+                bool chain = active;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const bool dense_k = TABLE ? bs[k] >= fp.thr_byte : rhos[k] >= thr;
+                    const bool need_k = chain && dense_k && ibs[k] < 255u;
+                    chain = chain && dense_k == last_dense;
+                    ahead_pre[k] = ahead_cone_wave(g, fp, need_k, ray.o + ray.d * ts[k], ray.d, ray.t_exit, lane, fp.cone_cos[lane & 7u] * 0.2f, fp.cone_sin[lane & 7u] * 0.2f);
+                }
+            } else if (PRE_AHEAD && pre_ahead) {
                 V3 starts[K];
                 bool need[K];
                 bool chain = active;
