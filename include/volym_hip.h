@@ -111,7 +111,9 @@ int volym_set_shard(volym_ctx* ctx, uint32_t rank, uint32_t world);
 
 /* --- resources: Simple::init (src/demos/simple/mod.rs:36-110) --------------------- */
 /* GpuVolume::init upload (src/gpu_resources/volume.rs:63-95): nx*ny*nz bytes, x fastest,
- * already padded/flipped by the host shim (volym_host.h volym_prepare_volume). */
+ * already padded/flipped by the host shim (volym_host.h volym_prepare_volume).  The caller's
+ * layout is always x fastest; on the device, volumes above 64 MiB are re-laid into 4x4x4 bricks
+ * (DESIGN.md section 3), which is invisible at this boundary. */
 int volym_set_volume(volym_ctx* ctx, const uint8_t* voxels, uint32_t nx, uint32_t ny,
                      uint32_t nz, int filter);
 /* GpuImportances::init upload (src/demos/simple/importance.rs:93-131); same dims. */
