@@ -584,7 +584,12 @@ static void render_pixel(const vo_scene* s, int gx, int gy, float out[4], vo_cou
 
         if (density >= par->density_threshold) cur_step = min_step;   /* wgsl:263-269 */
         else cur_step = fminf(base_step, cur_step * 1.5f);
-        if (density < par->density_threshold) { t += cur_step; continue; } /* wgsl:271-274 */
+        /* wgsl:271-274 tests `density < threshold`, the complement of wgsl:263 for every number.  A NaN density (smoothing
+         * on and all five taps outside the cube: 0/0, only on rays that graze a cube edge) would pass neither test and fall
+         * through to the shading with the *grown* step size.  WGSL leaves that case open ("implementations may assume that
+         * NaNs and infinities are not present at runtime ... an undefined value is produced instead"), so there is nothing
+         * to be faithful to; this restatement, oracle_np.py and the HIP kernels all take "a NaN density is not dense". */
+        if (!(density >= par->density_threshold)) { t += cur_step; continue; }
         k->n_dense++;
 
         float ca[4];

@@ -172,6 +172,48 @@ def test_bricked_layout_matches_oracle(oracle, volym_lib, bonsai64, filt):
                 _check(_render_gpu(ctx, cam2, par, variant), ref, "bricked dims %s v%d filter %d" % (rdims, variant, filt))
 
 
+def test_random_configurations(oracle, volym_lib):
+    """Seeded random scenes: non-cubic smooth-blob volumes with a random label map, ragged viewports, random orbit
+    poses, thresholds, step sizes, look-ahead depths, every flag, both filters, both volume layouts; the default kernel
+    rendered twice (the second frame runs the cost-ordered work lists with their depth-parallel items)."""
+    from volym_amd import _lib
+    rng = np.random.default_rng(20261004)
+    lut = oracle.tf_default_lut()
+    cases = 0
+    for case in range(36):
+        dims = tuple(int(v) for v in rng.integers(9, 49, 3))
+        n = dims[0] * dims[1] * dims[2]
+        zz, yy, xx = np.meshgrid(*(np.linspace(0.0, 1.0, d) for d in dims[::-1]), indexing="ij")
+        field = np.zeros(dims[::-1])
+        for _ in range(int(rng.integers(1, 5))):
+            c = rng.uniform(0.15, 0.85, 3)
+            r = rng.uniform(0.12, 0.45)
+            field = np.maximum(field, np.clip(1.0 - np.sqrt((xx - c[0]) ** 2 + (yy - c[1]) ** 2 + (zz - c[2]) ** 2) / r, 0.0, 1.0))
+        vol = np.clip(field * rng.uniform(120, 255) + rng.normal(0.0, 6.0, field.shape), 0, 255).astype(np.uint8).ravel()
+        imp = np.where(rng.random(n) < rng.uniform(0.0, 0.3), 255, rng.integers(0, 200, n)).astype(np.uint8)
+        W, H = int(rng.integers(17, 150)), int(rng.integers(9, 100))
+        cam = oracle.benchmark_camera_uniforms(W / H, float(rng.uniform(-180, 180)), float(rng.uniform(-70, 70)), float(rng.uniform(0.0, 1.5)))
+        flags = dict(zip(common.FLAG_NAMES, (int(b) for b in rng.integers(0, 2, 5))))
+        if case % 3 == 0:
+            flags.update(use_opacity=1, use_importance_coloring=0, use_importance_rendering=0)   # the specialised instantiation
+        par = oracle.make_parameters(density_threshold=float(rng.uniform(0.05, 0.6)), importance_check_ahead_steps=int(rng.integers(1, 12)),
+                                     raymarching_step_size=float(rng.choice([0.004, 0.007, 0.01, 0.013, 0.02, 0.033])), **flags)
+        filt = int(rng.integers(0, 2))
+        ref = oracle.render(vol, imp, dims, lut, cam, par, W, H, filter=filt)
+        for layout in (0, 1):
+            with _ctx(W, H) as ctx:
+                ctx.set_option(112, layout)
+                ctx.set_volume(vol, dims, filt)
+                ctx.set_importances(imp, dims)
+                ctx.set_transfer_function(lut)
+                ctx.set_option(105, 1)      # every marched tile becomes depth-parallel items in the second frame
+                for frame in range(2):
+                    _check(_render_gpu(ctx, cam, par, 2), ref,
+                           "random case %d dims %s %dx%d flags %s filter %d layout %d frame %d" % (case, dims, W, H, common.flag_id(flags), filt, layout, frame))
+                    cases += 1
+    assert cases == 36 * 4
+
+
 def test_ragged_viewport_and_tiny_volume(oracle, volym_lib):
     """Viewport not a multiple of 16 (guard wgsl:217-219), 1-voxel-thin and non-cubic volumes."""
     rng = np.random.default_rng(7)
