@@ -172,12 +172,13 @@ def test_bricked_layout_matches_oracle(oracle, volym_lib, bonsai64, filt):
                 _check(_render_gpu(ctx, cam2, par, variant), ref, "bricked dims %s v%d filter %d" % (rdims, variant, filt))
 
 
-def test_random_configurations(oracle, volym_lib):
+@pytest.mark.parametrize("seed", [20261004, 7, 424242])
+def test_random_configurations(oracle, volym_lib, seed):
     """Seeded random scenes: non-cubic smooth-blob volumes with a random label map, ragged viewports, random orbit
     poses, thresholds, step sizes, look-ahead depths, every flag, both filters, both volume layouts; the default kernel
     rendered twice (the second frame runs the cost-ordered work lists with their depth-parallel items)."""
     from volym_amd import _lib
-    rng = np.random.default_rng(20261004)
+    rng = np.random.default_rng(seed)
     lut = oracle.tf_default_lut()
     cases = 0
     for case in range(36):
@@ -209,7 +210,7 @@ def test_random_configurations(oracle, volym_lib):
                 ctx.set_option(105, 1)      # every marched tile becomes depth-parallel items in the second frame
                 for frame in range(2):
                     _check(_render_gpu(ctx, cam, par, 2), ref,
-                           "random case %d dims %s %dx%d flags %s filter %d layout %d frame %d" % (case, dims, W, H, common.flag_id(flags), filt, layout, frame))
+                           "seed %d case %d dims %s %dx%d flags %s filter %d layout %d frame %d" % (seed, case, dims, W, H, common.flag_id(flags), filt, layout, frame))
                     cases += 1
     assert cases == 36 * 4
 
