@@ -305,7 +305,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "volym_raymarch_pq_kernel<true,false,false,4,false>" if args.kernel == 2 else "volym_raymarch_kernel<%d,false,false>" % args.kernel,
+                "kernel": "volym_raymarch_pq_kernel<true,false,false,4,false,%s>" % ("true" if (args.layout == 1 or (args.layout < 0 and dims[0] * dims[1] * dims[2] > (64 << 20))) else "false") if args.kernel == 2 else "volym_raymarch_kernel<%d,false,false>" % args.kernel,
                 "kernel_avg_ms": kernel_ms, "launch_algorithmic_bytes": local_bytes,
                 "note": "algorithmic bytes = reference fetch count (n_vol*%d + n_imp) + 4 B/pixel; the 32 MiB working set is "
                         "Infinity-Cache resident, so HBM traffic << algorithmic bytes (DESIGN.md)" % b_vol,
