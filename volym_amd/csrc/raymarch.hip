@@ -477,7 +477,7 @@ static int reorder_by_cost(volym_ctx* c)
     const uint64_t tenths = c->dp_min_cost < -1 ? static_cast<uint64_t>(-c->dp_min_cost) : 15u;
     const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(64, tenths * total_cost / (10u * std::max(1u, resident_waves)) + 16));
     const uint32_t dp_thr = c->dp_min_cost < 0 ? adaptive : static_cast<uint32_t>(c->dp_min_cost);
-    const bool dp_ok = c->dp_min_cost != 0 && !(c->fp.flags & (F_LINEAR | F_GAUSSIAN | F_IMP_RENDERING));
+    const bool dp_ok = c->dp_min_cost != 0 && !(c->fp.flags & (F_LINEAR | F_GAUSSIAN));
     std::vector<std::pair<uint32_t, uint32_t>> keyed;      // (cost share, item)
     keyed.reserve(c->h_order.size() * 2);
     // 16x16 tiles whose four sub-tiles were all constant become one "super" fill item (bit 30)
@@ -803,19 +803,24 @@ static int launch_march(volym_ctx* c)
         const uint32_t want = (c->n_items + PQ_WAVES - 1) / PQ_WAVES;
         const uint32_t pgrid = c->order_grid ? c->order_grid : std::max(1u, std::min(want, static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu));
         const bool table = !(fp.flags & (F_LINEAR | F_GAUSSIAN));
-#define VOLYM_PQ_LAUNCH(T, KS, I, B)                                                                                             \
-    hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT && I, TRACE, KS, I, B>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,  \
+#define VOLYM_PQ_LAUNCH(T, KS, I, B, R)                                                                                          \
+    hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT && I, TRACE, KS, I, B, R>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,  \
                        c->d_imp, c->d_tables, c->d_df, c->d_order, c->n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
-        // IMP = false: opacity on and no importance mode (the common case); the instrumented launch always takes the general form
-        const bool no_imp = !COUNT && !(fp.flags & (F_IMP_COLORING | F_IMP_RENDERING)) && (fp.flags & F_OPACITY);
+        // IMP = false: opacity on and no importance colouring (the common cases), without (IR = false) or with (IR = true)
+        // importance rendering; the instrumented launch always takes the general form
+        const bool special = !COUNT && !(fp.flags & F_IMP_COLORING) && (fp.flags & F_OPACITY);
+        const bool no_imp = special && !(fp.flags & F_IMP_RENDERING);
+        const bool ir = special && (fp.flags & F_IMP_RENDERING);
         if (c->bricked) {
-            if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, true);
-            else if (table) VOLYM_PQ_LAUNCH(true, 4, true, true);
-            else VOLYM_PQ_LAUNCH(false, 1, true, true);
+            if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, true, false);
+            else if (table && ir) VOLYM_PQ_LAUNCH(true, 4, false, true, true);
+            else if (table) VOLYM_PQ_LAUNCH(true, 4, true, true, false);
+            else VOLYM_PQ_LAUNCH(false, 1, true, true, false);
         } else {
-            if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, false);
-            else if (table) VOLYM_PQ_LAUNCH(true, 4, true, false);
-            else VOLYM_PQ_LAUNCH(false, 1, true, false);
+            if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, false, false);
+            else if (table && ir) VOLYM_PQ_LAUNCH(true, 4, false, false, true);
+            else if (table) VOLYM_PQ_LAUNCH(true, 4, true, false, false);
+            else VOLYM_PQ_LAUNCH(false, 1, true, false, false);
         }
 #undef VOLYM_PQ_LAUNCH
         HIPCHK(c, hipGetLastError());

@@ -95,7 +95,7 @@ __device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, const H
     if (out_obj) return in_cube ? TILE_FILL_EMPTY : TILE_HIT_TEST;
     return TILE_MARCH;
 }
-template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true, bool BRICK = false>
+template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true, bool BRICK = false, bool IR = false>
 __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
     const uint8_t* __restrict__ df4, const uint32_t* __restrict__ order, uint32_t n_items, uint16_t* __restrict__ cost,
@@ -125,13 +125,16 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
 
     // IMP = false also pins the opacity flag of the common case so that its tests fold away; every other combination
     // runs the IMP = true instantiation
-    const uint32_t flags = IMP ? fp.flags : ((fp.flags & ~(F_IMP_COLORING | F_IMP_RENDERING | F_CONE)) | F_OPACITY);
+    // IR (with IMP = false): the same specialised paths with importance rendering on (opacity on, no importance colouring)
+    static_assert(!(IMP && IR), "IR specialises the IMP = false paths");
+    const uint32_t flags = IMP ? fp.flags : IR ? ((fp.flags & ~F_IMP_COLORING) | F_OPACITY | F_IMP_RENDERING)
+                                               : ((fp.flags & ~(F_IMP_COLORING | F_IMP_RENDERING | F_CONE)) | F_OPACITY);
     const bool linear = (flags & F_LINEAR) != 0u;
     const bool gauss = (flags & F_GAUSSIAN) != 0u;
     // IMP = false: instantiation for frames with both importance modes off (the reference's "Base" rows): the
     // look-ahead and importance-colouring code, its registers and its scalar state are compiled out
     const bool imp_coloring = IMP && (flags & F_IMP_COLORING) != 0u;
-    const bool imp_rendering = IMP && (flags & F_IMP_RENDERING) != 0u;
+    const bool imp_rendering = (IMP || IR) && (flags & F_IMP_RENDERING) != 0u;
     const bool need_imp = imp_coloring || imp_rendering;
 
     if (VOLYM_DEV_SWITCHES && (fp.dev & 16u)) return;                    // launch + dispatch only
@@ -501,11 +504,14 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         }
                     }
                     V3 my_pos[J];
-                    uint32_t my_b[J];
+                    uint32_t my_b[J], my_ib[J];
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
+                        my_ib[j] = 255u;
                         my_pos[j] = ray.o + ray.d * my_t[j];                 // wgsl:251
-                        my_b[j] = vol[nearest_offset(g, my_pos[j])];        // clamped offset: no guard needed
+                        const uint32_t off_j = nearest_offset(g, my_pos[j]);  // clamped offset: no guard needed
+                        my_b[j] = vol[off_j];
+                        if (IR) my_ib[j] = imp[off_j];
                     }
                     drain();
                     uint32_t cm = 0;                                         // class bits of the N samples (same in the quad)
@@ -518,6 +524,26 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         a4[j][1] = __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0x55, 0xf, 0xf, true));
                         a4[j][2] = __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0xaa, 0xf, 0xf, true));
                         a4[j][3] = __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0xff, 0xf, 0xf, true));
+                    }
+                    // importance rendering (wgsl:283-295): every lane looks ahead for its own samples; the verdicts travel like
+                    // the classes.  sm: samples that are dense but suppressed -- they advance the march and emit nothing.
+                    uint32_t sm = 0;
+                    if (IR) {
+                        bool need[J], ahead[J];
+#pragma unroll
+                        for (int j = 0; j < J; ++j) { need[j] = active && my_b[j] >= fp.thr_byte && my_ib[j] < 255u; ahead[j] = false; }
+                        if (flags & F_CONE) {
+#pragma unroll
+                            for (int j = 0; j < J; ++j)
+                                ahead[j] = ahead_cone_wave(g, fp, need[j], my_pos[j], ray.d, ray.t_exit, lane, fp.cone_cos[lane & 7u] * 0.2f, fp.cone_sin[lane & 7u] * 0.2f);
+                        } else {
+                            bool any_need = false;
+#pragma unroll
+                            for (int j = 0; j < J; ++j) any_need = any_need || need[j];
+                            if (__ballot(any_need) != 0ull) ahead_straight_multi<J>(g, fp, my_pos, need, ray.d, ray.t_exit, ahead);
+                        }
+#pragma unroll
+                        for (int j = 0; j < J; ++j) sm |= (static_cast<uint32_t>(__ballot(need[j] && ahead[j]) >> qsh) & 15u) << (4 * j);
                     }
                     // How many samples does the sequential march accept?  It stops (wgsl:250) at the first sample with
                     // t >= t_end or alpha >= 0.95, and the predicted positions hold up to and including the first sample
@@ -532,14 +558,14 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         const float w = (1.0f - a_run) * a4[sidx >> 2][sidx & 3];
                         if ((sidx & 3) == 0) my_w[sidx >> 2] = w;
                         else my_w[sidx >> 2] = kq == static_cast<uint32_t>(sidx & 3) ? w : my_w[sidx >> 2];
-                        a_run = ((cm >> sidx) & 1u) ? a_run + w : a_run;
+                        a_run = (((cm & ~sm) >> sidx) & 1u) ? a_run + w : a_run;
                         a_after[sidx] = a_run;
                     }
                     const uint32_t full = (1u << N) - 1u;
                     const uint32_t mism = cm ^ (last_dense ? full : 0u);
                     const uint32_t n_c = min(static_cast<uint32_t>(__builtin_ctz(mism | (1u << N))) + 1u, static_cast<uint32_t>(N));
                     const uint32_t n_acc = min(min(n_t, n_a), n_c);          // >= 1 on an active lane
-                    const uint32_t em = active ? (cm & ((1u << n_acc) - 1u)) : 0u;   // accepted dense samples emit
+                    const uint32_t em = active ? (cm & ~sm & ((1u << n_acc) - 1u)) : 0u;   // accepted dense samples emit, unless suppressed
                     bool my_emit[J];
 #pragma unroll
                     for (int j = 0; j < J; ++j) my_emit[j] = ((em >> (4 * j + kq)) & 1u) != 0u;
@@ -596,6 +622,24 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 const float a_k = imp_coloring ? s_ic_alpha[ib] : s_tf_tab[b].w;
                 const uint32_t quad_d = static_cast<uint32_t>(__ballot(dense_k) >> qsh) & 15u;
                 const uint32_t quad_c = static_cast<uint32_t>(__ballot(tk < t_end) >> qsh) & 15u;
+                // importance rendering (wgsl:283-295): every lane looks ahead for its own sample -- one chain per lane, or the
+                // 8 cone chains of 8 samples per round -- and the verdicts travel like the classes.  A sample that is not
+                // accepted in the end only cost fetches.
+                uint32_t quad_s = 0u;
+                if (imp_rendering && !imp_coloring) {
+                    const bool need_k = active && dense_k && ib < 255u;
+                    bool ahead_k;
+                    if (flags & F_CONE) {
+                        ahead_k = ahead_cone_wave(g, fp, need_k, pos, ray.d, ray.t_exit, lane, fp.cone_cos[lane & 7u] * 0.2f, fp.cone_sin[lane & 7u] * 0.2f);
+                    } else {
+                        const V3 starts[1] = {pos};
+                        const bool needs[1] = {need_k};
+                        bool founds[1];
+                        ahead_straight_multi<1>(g, fp, starts, needs, ray.d, ray.t_exit, founds);
+                        ahead_k = founds[0];
+                    }
+                    quad_s = static_cast<uint32_t>(__ballot(need_k && ahead_k) >> qsh) & 15u;
+                }
                 const int a_bits = __float_as_int(a_k);
                 const float a4[4] = {__int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0x00, 0xf, 0xf, true)),
                                      __int_as_float(__builtin_amdgcn_mov_dpp(a_bits, 0x55, 0xf, 0xf, true)),
@@ -614,7 +658,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                             } else {
                                 const bool dj = ((quad_d >> j) & 1u) != 0u;
                                 last = j;
-                                if (dj) {
+                                if (dj && ((quad_s >> j) & 1u) == 0u) {               // a suppressed sample only advances (wgsl:290-293)
                                     if (use_alpha_dp) {                               // wgsl:313-318
                                         const float w = (1.0f - alpha) * a4[j];
                                         if (static_cast<uint32_t>(j) == kq) { my_w = w; my_emit = true; }
@@ -686,8 +730,9 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                     // the clamped texel selection keeps every offset inside the volume, whatever t is: the byte gathers
                     // need no guard (a finished lane re-reads its last texels; nothing uses them)
                     if (TABLE) bs[k] = vol[offs[k]];
+                    if (IR) ibs[k] = imp[offs[k]];
                     if (active) {
-                        if (need_imp) ibs[k] = imp[offs[k]];
+                        if (!IR && need_imp) ibs[k] = imp[offs[k]];
                         if (!TABLE) {                                   // wgsl:253-259, all K densities in flight together
                             const V3 p = ray.o + ray.d * ts[k];
                             uint32_t cnt = 0;
@@ -712,12 +757,44 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
 #pragma unroll
                 for (int k = 0; k < K; ++k) a_tab[k] = s_tf_tab[bs[k]].w;
                 const bool predicted = last_dense;
+                // importance rendering (wgsl:283-295): the look-ahead of every sample that can still be accepted as dense,
+                // side by side (straight) or spread over the wave (cone); a suppressed sample only advances
+                bool supp[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) supp[k] = false;
+                if (IR) {
+                    bool need[K];
+                    bool chain = active;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const bool dense_k = bs[k] >= fp.thr_byte;
+                        need[k] = chain && dense_k && ibs[k] < 255u;
+                        chain = chain && dense_k == predicted;
+                    }
+                    if (flags & F_CONE) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k)
+                            supp[k] = ahead_cone_wave(g, fp, need[k], ray.o + ray.d * ts[k], ray.d, ray.t_exit, lane, fp.cone_cos[lane & 7u] * 0.2f, fp.cone_sin[lane & 7u] * 0.2f);
+                    } else {
+                        bool any_need = false;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) any_need = any_need || need[k];
+                        if (__ballot(any_need) != 0ull) {
+                            V3 starts[K];
+#pragma unroll
+                            for (int k = 0; k < K; ++k) starts[k] = ray.o + ray.d * ts[k];
+                            ahead_straight_multi<K>(g, fp, starts, need, ray.d, ray.t_exit, supp);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < K; ++k) supp[k] = supp[k] && need[k];
+                }
                 bool valid = active;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const bool go = valid && t < t_end && acc_a < 0.95f;             // wgsl:250
                     const bool dense = bs[k] >= fp.thr_byte;                          // <=> b/255 >= thr
-                    const bool emit = go && dense;
+                    const bool emit = go && dense && !supp[k];
                     const float w = (1.0f - acc_a) * a_tab[k];                        // wgsl:313-318
                     const V3 pos = ray.o + ray.d * t;                                 // == ps[k] while go
                     acc_a = emit ? acc_a + w : acc_a;
