@@ -20,12 +20,20 @@
 //     REAL classes and stop at the first misprediction.  Accepted samples are bit-identical to the
 //     sequential march (same f32 operations in the same order).
 //
-// Work distribution: persistent workgroups of PQ_WAVES waves, one or two per CU.  The host sorts this
-// rank's 8x8-pixel wave tiles centre-first (the orbit camera always targets the volume centre,
-// src/camera.rs:23, so the expensive tiles tend to be the central ones); workgroup b owns items
-// b, b+G, b+2G, ... (every workgroup gets the same mix of radii) and its waves take them in that order
-// through a ticket counter in LDS: dynamic balance inside the workgroup, no global atomics, nothing to
-// reset between launches, no inter-workgroup communication.
+// Work distribution: persistent workgroups of PQ_WAVES waves, one per CU (it owns the CU's LDS).  Every workgroup reads a
+// list of items -- workgroup b the entries b, b+G, b+2G, ... of `order` -- and its waves draw them through a ticket counter
+// in LDS: dynamic balance inside the workgroup, no global atomics, nothing to reset between launches.  The first frame of
+// a view runs the host's centre-first list (the orbit camera targets the volume centre, src/camera.rs:23) and records a
+// counted cost per tile; from the second frame of an unchanged view the host deals the items longest-processing-time
+// first (raymarch.hip reorder_by_cost), turns the most expensive tiles into depth-parallel quarter items (bit 31) and
+// constant 16x16 tiles into super fill items (bit 30).
+//
+// Item kinds and their loops (all bit-identical to the sequential march):
+//   * 8x8 tile, one lane per ray, K speculative samples per iteration ("classic");
+//   * 4x4 quarter tile, four lanes per ray ("depth-parallel"): for the long chains of dependent samples a frame ends on;
+//   * fill items: tiles the hulls prove constant.
+// Template parameters: TABLE (nearest filter without smoothing: density is a table of the byte), COUNT (instrumented),
+// TRACE (development), IMP (general flag handling) / IR (importance rendering on the specialised paths), BRICK (layout).
 //
 // Exact culling (results unchanged, DESIGN.md "Culling"):
 //   * no sample outside the AABB of the occupied macro cells can reach the threshold, so a ray is
