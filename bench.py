@@ -264,6 +264,12 @@ def main():
     frame_bytes = n_vol * b_vol + n_imp + 4 * W * H                           # whole frame (B_alg)
     achieved = local_bytes / (kernel_ms * 1e-3) / 1e9
 
+    # the instantiation launch_march picks for this workload (raymarch.hip): <TABLE, COUNT, TRACE, K, IMP, BRICK, IR>
+    continuous = bool(args.linear or args.gaussian)
+    bricked = args.layout == 1 or (args.layout < 0 and dims[0] * dims[1] * dims[2] > (64 << 20))
+    pq_kernel_name = "volym_raymarch_pq_kernel<%s,false,false,%d,%s,%s,%s>" % (
+        "false" if continuous else "true", 1 if continuous else 4, "true" if continuous else "false",
+        "true" if bricked else "false", "true" if (args.importance and not continuous) else "false")
     # HBM-side traffic of one launch: PMC counters cannot be read from inside this process; use the committed
     # rocprofv3 measurement of this exact workload when there is one (profiles/rNN_traffic.json)
     traffic, traffic_src = None, None
@@ -305,7 +311,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "volym_raymarch_pq_kernel<true,false,false,4,false,%s>" % ("true" if (args.layout == 1 or (args.layout < 0 and dims[0] * dims[1] * dims[2] > (64 << 20))) else "false") if args.kernel == 2 else "volym_raymarch_kernel<%d,false,false>" % args.kernel,
+                "kernel": pq_kernel_name if args.kernel == 2 else "volym_raymarch_kernel<%d,false,false>" % args.kernel,
                 "kernel_avg_ms": kernel_ms, "launch_algorithmic_bytes": local_bytes,
                 "note": "algorithmic bytes = reference fetch count (n_vol*%d + n_imp) + 4 B/pixel; the 32 MiB working set is "
                         "Infinity-Cache resident, so HBM traffic << algorithmic bytes (DESIGN.md)" % b_vol,
