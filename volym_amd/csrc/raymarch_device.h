@@ -329,44 +329,71 @@ __device__ __forceinline__ bool ahead_straight(const G& g, const FrameParams& fp
     return false;
 }
 
-// The straight look-ahead of up to K samples of one ray at once (uninstrumented launches): the probes of a sample
-// depend on its position only, not on the opacity accumulated before it, so the K chains of dependent importance fetches
-// run side by side instead of one after the other.  Same positions, same f32 operations per chain as ahead_straight; the
-// early exit of a chain only ever saved fetches, never changed the answer.
+// The straight look-ahead of up to K samples per lane, spread over the wave (uninstrumented launches): the samples that
+// need one are numbered across the wave (sample 0 of all lanes first, then sample 1, ...), their owners post
+// (lane, sample) in a 256-byte LDS mailbox, and lane l of round r walks the chain of candidate 64 r + l -- every lane
+// has a chain to walk as long as candidates remain, whoever owns them.  The sample's ray travels by cross-lane reads, the
+// answer by ballot.  Same positions and f32 operations per chain as ahead_straight; a chain's early exit only ever saved
+// fetches.  Every lane of the wave must call this.
 template <int K, class G>
-__device__ __forceinline__ void ahead_straight_multi(const G& g, const FrameParams& fp, const V3 (&start)[K], const bool (&need)[K], V3 dir,
-                                                     float t_exit, bool (&found)[K])
+__device__ __forceinline__ void ahead_straight_wave(const G& g, const FrameParams& fp, const bool (&need)[K], const float (&ts)[K], V3 o, V3 dir,
+                                                    float t_exit, uint32_t lane, uint8_t* mail, bool (&found)[K])
 {
-    const int n = static_cast<int>(fp.ahead_steps);
-    V3 pos[K];
-    float step[K];
-    bool live[K];
+    static_assert(K <= 4, "two bits for the sample index");
+    uint32_t my_idx[K];
+    uint32_t total = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        pos[k] = start[k];
-        step[k] = (t_exit - length_exact(start[k])) / static_cast<float>(n);
-        live[k] = need[k];
+        const unsigned long long m = __ballot(need[k]);
+        my_idx[k] = total + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+        total += static_cast<uint32_t>(__popcll(m));
         found[k] = false;
     }
-    constexpr int B = 2;
-    for (int i = 0; i < n; i += B) {
-        uint32_t ib[K][B];
+    if (total == 0u) return;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < B; ++j)
+    for (int k = 0; k < K; ++k)
+        if (need[k]) mail[my_idx[k]] = static_cast<uint8_t>(lane | (static_cast<uint32_t>(k) << 6));
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n = static_cast<int>(fp.ahead_steps);
+    for (uint32_t r = 0; r * 64u < total; ++r) {
+        const uint32_t j = r * 64u + lane;
+        const bool job = j < total;
+        const uint32_t code = mail[job ? j : 0u];
+        const int owner = static_cast<int>(code & 63u);
+        const uint32_t kk = code >> 6;
+        const V3 o0 = v3(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
+        const V3 d0 = v3(__shfl(dir.x, owner, 64), __shfl(dir.y, owner, 64), __shfl(dir.z, owner, 64));
+        const float t_exit0 = __shfl(t_exit, owner, 64);
+        float t0 = __shfl(ts[0], owner, 64);
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                pos[k] = pos[k] + dir * step[k];
-                ib[k][j] = g.imp[nearest_offset(g, pos[k])];       // clamped offset: safe wherever pos is
-            }
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-#pragma unroll
-            for (int j = 0; j < B; ++j)
-                if (live[k] && i + j < n && ib[k][j] >= 128u) { found[k] = true; live[k] = false; }   // i/255 >= 0.5  <=>  i >= 128
-            any = any || live[k];
+        for (int k = 1; k < K; ++k) {
+            const float tk = __shfl(ts[k], owner, 64);
+            t0 = kk == static_cast<uint32_t>(k) ? tk : t0;
         }
-        if (__ballot(any) == 0ull) break;
+        const V3 p0 = o0 + d0 * t0;                                                // the sample position, as its owner computes it (wgsl:251)
+        const float step = (t_exit0 - length_exact(p0)) / static_cast<float>(n);  // wgsl:145-147
+        const V3 ds = d0 * step;
+        V3 pos = p0;
+        bool live = job, hit = false;
+        for (int i = 0; i < n; i += VOLYM_PROBE_BATCH) {
+            uint32_t ib[VOLYM_PROBE_BATCH];
+#pragma unroll
+            for (int b = 0; b < VOLYM_PROBE_BATCH; ++b) {
+                pos = pos + ds;
+                ib[b] = g.imp[nearest_offset(g, pos)];                             // clamped offset: safe wherever pos is
+            }
+#pragma unroll
+            for (int b = 0; b < VOLYM_PROBE_BATCH; ++b)
+                if (live && i + b < n && ib[b] >= 128u) { hit = true; live = false; }   // i/255 >= 0.5  <=>  i >= 128
+            if (__ballot(live) == 0ull) break;
+        }
+        const unsigned long long hits = __ballot(hit);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (need[k] && (my_idx[k] >> 6) == r) found[k] = ((hits >> (my_idx[k] & 63u)) & 1ull) != 0ull;
     }
 }
 

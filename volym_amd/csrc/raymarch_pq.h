@@ -128,6 +128,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     __shared__ uint32_t s_qm[PQ_WAVES][PQ_QCAP];
     __shared__ float s_qr[TABLE ? 1 : PQ_WAVES][TABLE ? 1 : PQ_QCAP];
     __shared__ uint32_t s_acc[PQ_WAVES][3][64];
+    __shared__ uint8_t s_mail[(IMP || IR) ? PQ_WAVES : 1][(IMP || IR) ? 256 : 1];   // look-ahead candidates of a wave (ahead_straight_wave)
     __shared__ uint32_t s_next_ticket;
     __shared__ uint32_t s_items[PQ_ITEMS_LDS];          // this workgroup's work list (items b, b+G, ...)
 
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     uint32_t* const acc_r = s_acc[wave][0];
     uint32_t* const acc_g = s_acc[wave][1];
     uint32_t* const acc_b = s_acc[wave][2];
+    uint8_t* const mail = s_mail[(IMP || IR) ? wave : 0];
 
     uint32_t n_vol = 0, n_imp = 0, n_steps = 0, n_dense = 0, n_hit = 0;
     const V3 eye = v3(fp.eye[0], fp.eye[1], fp.eye[2]);
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                             bool any_need = false;
 #pragma unroll
                             for (int j = 0; j < J; ++j) any_need = any_need || need[j];
-                            if (__ballot(any_need) != 0ull) ahead_straight_multi<J>(g, fp, my_pos, need, ray.d, ray.t_exit, ahead);
+                            if (__ballot(any_need) != 0ull) ahead_straight_wave<J>(g, fp, need, my_t, ray.o, ray.d, ray.t_exit, lane, mail, ahead);
                         }
 #pragma unroll
                         for (int j = 0; j < J; ++j) sm |= (static_cast<uint32_t>(__ballot(need[j] && ahead[j]) >> qsh) & 15u) << (4 * j);
@@ -640,10 +642,10 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                     if (flags & F_CONE) {
                         ahead_k = ahead_cone_wave(g, fp, need_k, pos, ray.d, ray.t_exit, lane, fp.cone_cos[lane & 7u] * 0.2f, fp.cone_sin[lane & 7u] * 0.2f);
                     } else {
-                        const V3 starts[1] = {pos};
+                        const float tks[1] = {tk};
                         const bool needs[1] = {need_k};
                         bool founds[1];
-                        ahead_straight_multi<1>(g, fp, starts, needs, ray.d, ray.t_exit, founds);
+                        ahead_straight_wave<1>(g, fp, needs, tks, ray.o, ray.d, ray.t_exit, lane, mail, founds);
                         ahead_k = founds[0];
                     }
                     quad_s = static_cast<uint32_t>(__ballot(need_k && ahead_k) >> qsh) & 15u;
@@ -787,12 +789,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         bool any_need = false;
 #pragma unroll
                         for (int k = 0; k < K; ++k) any_need = any_need || need[k];
-                        if (__ballot(any_need) != 0ull) {
-                            V3 starts[K];
-#pragma unroll
-                            for (int k = 0; k < K; ++k) starts[k] = ray.o + ray.d * ts[k];
-                            ahead_straight_multi<K>(g, fp, starts, need, ray.d, ray.t_exit, supp);
-                        }
+                        if (__ballot(any_need) != 0ull) ahead_straight_wave<K>(g, fp, need, ts, ray.o, ray.d, ray.t_exit, lane, mail, supp);
                     }
 #pragma unroll
                     for (int k = 0; k < K; ++k) supp[k] = supp[k] && need[k];
@@ -834,24 +831,15 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                     ahead_pre[k] = ahead_cone_wave(g, fp, need_k, ray.o + ray.d * ts[k], ray.d, ray.t_exit, lane, fp.cone_cos[lane & 7u] * 0.2f, fp.cone_sin[lane & 7u] * 0.2f);
                 }
             } else if (PRE_AHEAD && pre_ahead) {
-                V3 starts[K];
                 bool need[K];
                 bool chain = active;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const bool dense_k = TABLE ? bs[k] >= fp.thr_byte : rhos[k] >= thr;
-                    starts[k] = ray.o + ray.d * ts[k];
                     need[k] = chain && dense_k && ibs[k] < 255u;
                     chain = chain && dense_k == last_dense;
                 }
-                bool any_need = false;
-#pragma unroll
-                for (int k = 0; k < K; ++k) any_need = any_need || need[k];
-                if (__ballot(any_need) != 0ull) ahead_straight_multi<K>(g, fp, starts, need, ray.d, ray.t_exit, ahead_pre);
-                else {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) ahead_pre[k] = false;
-                }
+                ahead_straight_wave<K>(g, fp, need, ts, ray.o, ray.d, ray.t_exit, lane, mail, ahead_pre);
             }
             bool valid = active;
 #pragma unroll
