@@ -17,18 +17,20 @@ def main():
     ap.add_argument("--bands", type=int, default=0)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--linear", action="store_true")
+    ap.add_argument("--gaussian", action="store_true")
     args = ap.parse_args()
     W, H = args.width, args.height
     dims = (256, 256, 256)
     vol = scene.prepare_volume(synth.synth_bonsai(256), dims, True)
-    params = scene.StateParameters.benchmark().replace(raymarching_step_size=0.01)
+    params = scene.StateParameters.benchmark().replace(raymarching_step_size=0.01, use_gaussian_smoothing=1 if args.gaussian else 0)
     state = scene.State.with_parameters(W / H, params)
     state.update()
     L = _lib.lib()
     L.volym_dev_wave_trace.restype = C.c_int
     L.volym_dev_wave_trace.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
     with demo.GpuContext(W, H, 0) as ctx:
-        ctx.set_volume(vol, dims)
+        ctx.set_volume(vol, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
         ctx.set_importances(np.zeros(256 ** 3, np.uint8), dims)
         ctx.set_transfer_function(scene.default_lut())
         ctx.set_option(_lib.OPT_KERNEL, args.kernel)

@@ -477,7 +477,7 @@ static int reorder_by_cost(volym_ctx* c)
     const uint64_t tenths = c->dp_min_cost < -1 ? static_cast<uint64_t>(-c->dp_min_cost) : 15u;
     const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(64, tenths * total_cost / (10u * std::max(1u, resident_waves)) + 16));
     const uint32_t dp_thr = c->dp_min_cost < 0 ? adaptive : static_cast<uint32_t>(c->dp_min_cost);
-    const bool dp_ok = c->dp_min_cost != 0 && !(c->fp.flags & (F_LINEAR | F_GAUSSIAN));
+    const bool dp_ok = c->dp_min_cost != 0;
     std::vector<std::pair<uint32_t, uint32_t>> keyed;      // (cost share, item)
     keyed.reserve(c->h_order.size() * 2);
     // 16x16 tiles whose four sub-tiles were all constant become one "super" fill item (bit 30)

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
       for (uint32_t sub_iter = 0; sub_iter < n_sub; ++sub_iter) {
         const uint32_t raw = is_super ? ((raw0 & 0x3fffffffu) * 4u + sub_iter) : raw0;
         const bool is_quarter = (raw >> 31) != 0u;
-        const bool dp = is_quarter && TABLE && !COUNT;
+        const bool dp = is_quarter && !COUNT;
         const uint32_t item = is_quarter ? ((raw & 0x7fffffffu) >> 2) : raw;
         const uint32_t quarter = raw & 3u;
         if (is_quarter && !dp && quarter != 0u) continue;   // instrumented launch: quarter 0 stands for the whole tile
@@ -625,11 +625,20 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 const float tk = kq == 0u ? ts4[0] : (kq == 1u ? ts4[1] : (kq == 2u ? ts4[2] : ts4[3]));
                 const V3 pos = ray.o + ray.d * tk;                    // wgsl:251
                 const uint32_t off = nearest_offset(g, pos);
-                uint32_t b = vol[off], ib = 0;                         // clamped offset: no guard needed
+                uint32_t b = 0, ib = 0;
+                float rho_k = 0.0f;
+                if (TABLE) b = vol[off];                               // clamped offset: no guard needed
                 if (active && need_imp) ib = imp[off];
-                drain();
-                const bool dense_k = b >= fp.thr_byte;                // <=> b/255 >= thr
-                const float a_k = imp_coloring ? s_ic_alpha[ib] : s_tf_tab[b].w;
+                if (!TABLE && active) {                                // wgsl:253-259
+                    uint32_t cnt = 0;
+                    rho_k = gauss ? sample_density_smoothed<false>(g, s_rho, linear, fp, pos, ray.d, cnt) : sample_density(g, s_rho, linear, pos);
+                }
+                if (TABLE) drain();                                    // continuous-rho modes shade inside append (registers)
+                const bool dense_k = TABLE ? b >= fp.thr_byte : rho_k >= thr;   // b/255 >= thr; a NaN density is not dense
+                float a_k;
+                if (imp_coloring) a_k = s_ic_alpha[ib];
+                else if (TABLE) a_k = s_tf_tab[b].w;
+                else a_k = dense_k ? 1.0f - wgsl_pow(1.0f - sample_tf(s_lut, fp.tf_n, rho_k).w, fp.alpha_y) : 0.0f;   // wgsl:314
                 const uint32_t quad_d = static_cast<uint32_t>(__ballot(dense_k) >> qsh) & 15u;
                 const uint32_t quad_c = static_cast<uint32_t>(__ballot(tk < t_end) >> qsh) & 15u;
                 // importance rendering (wgsl:283-295): every lane looks ahead for its own sample -- one chain per lane, or the
@@ -695,7 +704,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                     acc_a = alpha;
                     if (finished) active = false;
                 }
-                append(my_emit, pos, my_w, own | (b << 8) | (ib << 16), 0.0f);
+                append(my_emit, pos, my_w, own | (b << 8) | (ib << 16), rho_k);
                 if (TRACE) tm_samp += PQ_TICK() - tm_mark;
             }
             }
