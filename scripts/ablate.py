@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--prio", type=int, nargs="*", default=[100603])
     ap.add_argument("--only-quarters", type=int, default=0)
     ap.add_argument("--dev", type=int, nargs="*", default=[0])
+    ap.add_argument("--linear", action="store_true")
+    ap.add_argument("--gaussian", action="store_true")
     ap.add_argument("--balance", type=int, default=20050)
     args = ap.parse_args()
     W, H = args.width, args.height
@@ -41,7 +43,7 @@ def main():
     raw = synth.synth_bonsai(256)
     vol = scene.prepare_volume(raw, dims, True)
     zeros = np.zeros(256 ** 3, np.uint8)
-    params = scene.StateParameters.benchmark().replace(raymarching_step_size=args.step)
+    params = scene.StateParameters.benchmark().replace(raymarching_step_size=args.step, use_gaussian_smoothing=1 if args.gaussian else 0)
     state = scene.State.with_parameters(W / H, params)
     state.update()
     pu = state.parameter_uniforms()
@@ -56,7 +58,7 @@ def main():
         ctx.set_transfer_function(scene.default_lut())
         for name in args.cases:
             v, cu = cases[name]
-            ctx.set_volume(v, dims)
+            ctx.set_volume(v, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
             for k in args.kernels:
                 for b, ks, cl, fb in [(b, ks, cl, fb) for b in (args.bands if k != 2 else args.wgs) for ks in (args.kspec if k == 2 else [1]) for cl in (args.cull if k == 2 else [1]) for fb in (args.feedback if k == 2 else [0])]:
                   for dpc, fine in [(d, f) for d in (args.dp if k == 2 else [0]) for f in (args.prio if k == 2 else [0])]:

@@ -474,7 +474,10 @@ static int reorder_by_cost(volym_ctx* c)
     for (uint32_t item : c->h_order) total_cost += cost[item];
     const uint32_t resident_waves = static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu * PQ_WAVES;
     // dp_min_cost < 0 encodes the factor in tenths (-20 = 2.0 x fair share, the default -1 means 2.0)
-    const uint64_t tenths = c->dp_min_cost < -1 ? static_cast<uint64_t>(-c->dp_min_cost) : 15u;
+    // measured optimum: 1.5x for the table mode, 1.2x for the continuous-rho modes (their classic loop speculates only two
+    // samples deep, a depth-parallel item four)
+    const bool continuous = (c->fp.flags & (F_LINEAR | F_GAUSSIAN)) != 0u;
+    const uint64_t tenths = c->dp_min_cost < -1 ? static_cast<uint64_t>(-c->dp_min_cost) : (continuous ? 12u : 15u);
     const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(64, tenths * total_cost / (10u * std::max(1u, resident_waves)) + 16));
     const uint32_t dp_thr = c->dp_min_cost < 0 ? adaptive : static_cast<uint32_t>(c->dp_min_cost);
     const bool dp_ok = c->dp_min_cost != 0;
