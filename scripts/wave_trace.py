@@ -19,11 +19,13 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--linear", action="store_true")
     ap.add_argument("--gaussian", action="store_true")
+    ap.add_argument("--imp-coloring", action="store_true")
+    ap.add_argument("--no-opacity", action="store_true")
     args = ap.parse_args()
     W, H = args.width, args.height
     dims = (256, 256, 256)
     vol = scene.prepare_volume(synth.synth_bonsai(256), dims, True)
-    params = scene.StateParameters.benchmark().replace(raymarching_step_size=0.01, use_gaussian_smoothing=1 if args.gaussian else 0)
+    params = scene.StateParameters.benchmark().replace(raymarching_step_size=0.01, use_gaussian_smoothing=1 if args.gaussian else 0, use_importance_coloring=1 if args.imp_coloring else 0, use_opacity=0 if args.no_opacity else 1)
     state = scene.State.with_parameters(W / H, params)
     state.update()
     L = _lib.lib()
