@@ -103,6 +103,8 @@ def main():
                     help="0 direct (BASELINE configs[1]), 1 macro-cell, 2 persistent + LDS staging + shading queue (configs[2], default)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the driver's runs) or gloo (rehearsal on one device)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
+    ap.add_argument("--frames-per-gather", type=int, default=4, help="N > 1, packed shards: frames batched into one collective")
+    ap.add_argument("--full-gather", action="store_true", help="N > 1: gather whole shards instead of packed ones (only the tiles that are not constant)")
     ap.add_argument("--linear", action="store_true", help="trilinear volume filter (north_star mode)")
     ap.add_argument("--importance", action="store_true")
     ap.add_argument("--gaussian", action="store_true", help="use_gaussian_smoothing = 1 (the interactive default, src/state.rs:50)")
@@ -171,38 +173,89 @@ def main():
 
     shard_bytes = ctx.shard_bytes()
     nbuf = 4       # frames in flight: frame i's gather overlaps the marches of frames i+1..i+3
+    frame = torch.empty(W * H * 4, dtype=torch.uint8, device=dev)
+    packed_mode = world > 1 and not args.full_gather
+    msg_bytes, packed_tiles = shard_bytes, None
     if world > 1:
         shards = [torch.empty(shard_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        if packed_mode:
+            # Most 16x16 tiles of a frame are constant (outside the silhouette): the gather moves a header plus the tiles
+            # that are not (volym_pack_shard).  One untimed frame sizes the messages: the maximum over the ranks of the
+            # number of stored tiles (the view is static; a tile that found no room would raise the overflow flag).
+            cap = ctx.packed_shard_bytes(1 << 30)
+            probe = torch.empty(cap, dtype=torch.uint8, device=dev)
+            ctx.bind_output(shards[0].data_ptr(), frame.data_ptr())
+            ctx.compute_pass()
+            ctx.pack_shard(probe.data_ptr(), cap)
+            used, _ = ctx.packed_tiles()
+            t = torch.tensor([used], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            packed_tiles = int(t.item())
+            msg_bytes = ctx.packed_shard_bytes(packed_tiles)
+            del probe
+        # frames per collective: launching a collective from Python costs more than a rank's march of a 1/8 frame, so the
+        # packed shards of F consecutive frames travel together (frame f of a batch sits at offset f * msg_bytes)
+        F = max(1, args.frames_per_gather) if packed_mode else 1
+        if packed_mode:
+            packed = [torch.empty(F * msg_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         # only the root consumes the frame: a rooted gather = direct sends to rank 0 over separate xGMI links
-        # (a ring all_gather would move 7x the bytes through every link; the message is 1 MB per rank at 1080p)
-        gathered = [torch.empty(shard_bytes * world, dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(nbuf)]
-        gather_lists = [list(g.view(world, shard_bytes).unbind(0)) if g is not None else None for g in gathered]
-    frame = torch.empty(W * H * 4, dtype=torch.uint8, device=dev)
+        # (a ring all_gather would move 7x the bytes through every link)
+        gathered = [torch.empty(F * msg_bytes * world, dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(nbuf)]
+        gather_lists = [list(g.view(world, F * msg_bytes).unbind(0)) if g is not None else None for g in gathered]
     ctx.bind_output(shards[0].data_ptr() if world > 1 else None, frame.data_ptr())
 
     pending = [None] * nbuf
+    filled = [0] * nbuf          # packed mode: frames of the batch in buffer b that have been rendered
+    issued = {"frames": 0}       # frames issued so far (the batch and slot of the next one follow from it)
 
-    def one_frame(i):
+    def assemble(b):
+        if packed_mode:
+            for f in range(filled[b]):
+                ctx.assemble_packed(gathered[b].data_ptr() + f * msg_bytes, F * msg_bytes)
+        else:
+            ctx.assemble(gathered[b].data_ptr())
+
+    def retire(b):
+        if pending[b] is not None:          # buffer b's previous gather + assemble must be done before it is reused
+            pending[b].wait()
+            if rank == 0:
+                assemble(b)
+            pending[b] = None
+            filled[b] = 0
+
+    def one_frame(_i):
         if world == 1:
             ctx.compute_pass()
             return
-        b = i % nbuf
-        if pending[b] is not None:          # buffer b's previous gather + assemble must be done
-            pending[b].wait()
-            if rank == 0:
-                ctx.assemble(gathered[b].data_ptr())
-            pending[b] = None
-        ctx.bind_output(shards[b].data_ptr(), frame.data_ptr())
-        ctx.compute_pass()
-        pending[b] = dist.gather(shards[b], gather_lists[b], dst=0, async_op=True)
+        i = issued["frames"]
+        issued["frames"] = i + 1
+        if packed_mode:
+            b, f = (i // F) % nbuf, i % F
+            if f == 0:
+                retire(b)
+            ctx.compute_pass()              # into shards[0]: the pack below reads it before the next march starts (same stream)
+            ctx.pack_shard(packed[b].data_ptr() + f * msg_bytes, msg_bytes)
+            filled[b] = f + 1
+            if f == F - 1:
+                pending[b] = dist.gather(packed[b], gather_lists[b], dst=0, async_op=True)
+        else:
+            b = i % nbuf
+            retire(b)
+            ctx.bind_output(shards[b].data_ptr(), frame.data_ptr())
+            ctx.compute_pass()
+            pending[b] = dist.gather(shards[b], gather_lists[b], dst=0, async_op=True)
 
     def drain():
+        if world == 1:
+            return
+        if packed_mode:                     # a batch that is not full yet still has to travel
+            i = issued["frames"]
+            if i % F != 0:
+                b = (i // F) % nbuf
+                pending[b] = dist.gather(packed[b], gather_lists[b], dst=0, async_op=True)
+                issued["frames"] = (i // F + 1) * F
         for b in range(nbuf):
-            if pending[b] is not None:
-                pending[b].wait()
-                if rank == 0:
-                    ctx.assemble(gathered[b].data_ptr())
-                pending[b] = None
+            retire(b)
 
     for i in range(args.warmup):
         one_frame(i)
@@ -247,6 +300,11 @@ def main():
             ref = torch.from_numpy(solo.read_rgba8().reshape(-1))
             solo.close()
             gather_check = "ok" if bool(torch.equal(assembled.cpu(), ref)) else "MISMATCH"
+        if packed_mode:                      # no rank may have run out of room in its packed shard
+            over = torch.tensor([ctx.packed_tiles()[1]], dtype=torch.int64, device=dev)
+            dist.all_reduce(over, op=dist.ReduceOp.MAX)
+            if rank == 0 and int(over.item()) != 0:
+                gather_check = "OVERFLOW"
         dist.barrier()
 
     # ---- roofline of the dominant kernel: HIP events on the kernel's stream, algorithmic bytes from the
@@ -303,6 +361,7 @@ def main():
                                (", importance look-ahead %s" % ("cone" if args.cone else "straight") if args.importance else "") + (", gaussian smoothing" if args.gaussian else ""),
                                {0: "direct", 1: "macro-cell", 2: "persistent+LDS-staged+queue"}[args.kernel], 1 if args.kernel == 0 else 2),
                 "viewport": [W, H], "volume": list(dims), "tile_sharding": "interleaved 16x16 tiles, k %% %d" % world,
+                "gather": (None if world == 1 else ("packed shards: %d bytes per rank and frame (header + %d tiles that are not constant; a whole shard is %d bytes)" % (msg_bytes, packed_tiles, shard_bytes)) if packed_mode else ("whole shards: %d bytes per rank and frame" % shard_bytes)),
             },
             "gather_check": gather_check,
             "achieved_gbs": frame_bytes * args.steps / dt / 1e9,

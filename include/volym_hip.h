@@ -152,6 +152,18 @@ int volym_bind_output(volym_ctx* ctx, void* shard_rgba8, void* frame_rgba8);
 /* Root side of the image gather: `gathered` = world shards back to back in rank order
  * (device memory, world * volym_shard_bytes() bytes) -> raster W*H*4 in the frame buffer. */
 int volym_assemble(volym_ctx* ctx, const void* gathered);
+/* Packed shards (new; the reference has no multi-GPU path): most 16x16 tiles of a frame are constant -- outside the
+ * volume's silhouette -- and the gather only has to move the others.  volym_pack_shard enqueues, after a
+ * volym_compute_pass, the compaction of the bound shard into `packed`: a header (one {slot | constant flag, value} pair per
+ * local tile) followed by the 1 KiB tiles that are not constant; a tile that finds no room sets the overflow flag.
+ * volym_packed_shard_bytes(ctx, tiles): bytes of a packed shard with room for `tiles` tiles (tiles >= local tiles: always
+ * enough).  volym_packed_tiles: synchronises and reports how many tiles the last pack stored (size the steady-state buffers
+ * with the maximum over the ranks).  volym_assemble_packed: root side, `gathered` = world packed shards `stride_bytes`
+ * apart in rank order -> the raster in the frame buffer. */
+size_t volym_packed_shard_bytes(const volym_ctx* ctx, uint32_t tiles);
+int volym_pack_shard(volym_ctx* ctx, void* packed_device, size_t capacity_bytes);
+int volym_packed_tiles(volym_ctx* ctx, uint32_t* tiles_used, uint32_t* overflowed);
+int volym_assemble_packed(volym_ctx* ctx, const void* gathered_device, size_t stride_bytes);
 /* Host-memory conveniences for callers without a device-side collective (tests, the CLI):
  * copy this context's shard out (volym_shard_bytes() bytes, padding zeroed) / assemble from
  * world shards held in host memory. */

@@ -467,6 +467,70 @@ def test_shard_layout_matches_host_mirror(oracle, volym_lib):
             assert np.array_equal(sharding.assemble(np.concatenate(shards), W, H, world), full)
 
 
+def test_packed_shards_round_trip(oracle, volym_lib):
+    """volym_pack_shard / volym_assemble_packed: the gather moves only the tiles that are not constant, and the root
+    rebuilds the frame one context renders alone.  Virtual ranks on one GPU; buffers sized with the maximum number of
+    stored tiles over the ranks, as bench.py does; a buffer one tile short must raise the overflow flag.  Device memory
+    for the packed shards is borrowed from a scratch context's frame buffer (no torch in this process)."""
+    from volym_amd import _lib, demo, scene
+    raw, labels = common.bonsai(64)
+    dims = (64, 64, 64)
+    W, H = 310, 170                                         # ragged: partial tiles on both edges; most tiles outside the silhouette
+    cam = oracle.benchmark_camera_uniforms(W / H)
+    cu = _lib.CameraUniforms.from_buffer_copy(bytes(cam))
+    pu = _lib.ParameterUniforms.from_buffer_copy(bytes(oracle.make_parameters()))
+    volume = scene.prepare_volume(raw, dims, True)
+    zeros = np.zeros(64 ** 3, np.uint8)
+
+    def make(rank, world):
+        c = demo.GpuContext(W, H, 0)
+        c.set_shard(rank, world)
+        c.set_volume(volume, dims, 0)
+        c.set_importances(zeros, dims)
+        c.set_transfer_function(scene.default_lut())
+        c.update(cu, pu)
+        return c
+
+    with make(0, 1) as solo:
+        solo.compute_pass()
+        solo.sync()
+        full = solo.read_rgba8()
+    n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    with demo.GpuContext(2048, 1024, 0) as scratch:          # 8 MiB of device memory
+        mem, mem_bytes = scratch.frame_device_ptr(), 2048 * 1024 * 4
+        for world in (2, 3, 5):
+            ctxs = [make(r, world) for r in range(world)]
+            try:
+                cap = ctxs[0].packed_shard_bytes(1 << 30)      # room for every tile
+                assert world * cap <= mem_bytes
+                used = []
+                for r, c in enumerate(ctxs):
+                    c.compute_pass()
+                    c.pack_shard(mem + r * cap, cap)
+                    u, over = c.packed_tiles()
+                    assert over == 0 and 0 < u <= c.local_tiles()
+                    used.append(u)
+                assert sum(used) < n_tiles // 2                 # the point of the exercise
+                stride = ctxs[0].packed_shard_bytes(max(used))
+                for frame in range(3):                          # the slot counters alternate between launches
+                    for r, c in enumerate(ctxs):
+                        c.compute_pass()
+                        c.pack_shard(mem + r * stride, stride)
+                        u, over = c.packed_tiles()
+                        assert (u, over) == (used[r], 0)
+                    root = ctxs[0]
+                    root.assemble_packed(mem, stride)
+                    root.sync()
+                    assert np.array_equal(root.read_rgba8(), full), (world, frame)
+                short = ctxs[0].packed_shard_bytes(used[0] - 1)
+                ctxs[0].compute_pass()
+                ctxs[0].pack_shard(mem, short)
+                assert ctxs[0].packed_tiles()[1] == 1
+            finally:
+                for c in ctxs:
+                    c.close()
+
+
 def test_cli_benchmark_and_run(volym_lib, tmp_path):
     """`python -m volym_amd benchmark` writes the reference's 28-row CSV (src/main.rs:71-85, :178-345);
     `run simple` writes the screenshot PNG of the interactive default view."""

@@ -135,6 +135,10 @@ SIGNATURES = {
     "volym_frame_device_ptr": (C.c_void_p, [_ctx]),
     "volym_bind_output": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
     "volym_assemble": (C.c_int, [_ctx, C.c_void_p]),
+    "volym_packed_shard_bytes": (C.c_size_t, [_ctx, C.c_uint32]),
+    "volym_pack_shard": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
+    "volym_packed_tiles": (C.c_int, [_ctx, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "volym_assemble_packed": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
     "volym_read_shard": (C.c_int, [_ctx, _u8p]),
     "volym_assemble_host": (C.c_int, [_ctx, _u8p]),
     "volym_stats_pass": (C.c_int, [_ctx, C.POINTER(Stats)]),

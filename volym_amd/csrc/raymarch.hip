@@ -61,6 +61,8 @@ struct volym_ctx {
     uint32_t* d_frame = nullptr;
     float4* d_f32 = nullptr;
     uint8_t* d_gather_tmp = nullptr;
+    uint32_t* d_pack_counters = nullptr;   // volym_pack_shard: slot counters of even / odd launches, overflow flag
+    uint32_t pack_parity = 0;
     size_t gather_tmp_bytes = 0;
     Counters* d_counters = nullptr;
     uint4* d_trace = nullptr;   // development aid, see volym_dev_wave_trace
@@ -194,7 +196,7 @@ void volym_destroy(volym_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_vol); (void)hipFree(c->d_imp); (void)hipFree(c->d_tables); (void)hipFree(c->d_mc); (void)hipFree(c->d_df);
     (void)hipFree(c->d_shard_own); (void)hipFree(c->d_frame_own); (void)hipFree(c->d_f32);
-    (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_counters); (void)hipFree(c->d_order); (void)hipFree(c->d_cost); (void)hipFree(c->d_aabb);
+    (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_pack_counters); (void)hipFree(c->d_counters); (void)hipFree(c->d_order); (void)hipFree(c->d_cost); (void)hipFree(c->d_aabb);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -900,6 +902,55 @@ int volym_read_shard(volym_ctx* c, uint8_t* out)
     HIPCHK(c, hipMemcpyAsync(out, c->d_shard, used, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (total > used) std::memset(out + used, 0, total - used);
+    return VOLYM_OK;
+}
+
+size_t volym_packed_shard_bytes(const volym_ctx* c, uint32_t tiles)
+{
+    if (!c) return 0u;
+    return pack_header_bytes(c->shard_tiles) + static_cast<size_t>(std::min(tiles, c->shard_tiles)) * 1024u;
+}
+
+int volym_pack_shard(volym_ctx* c, void* packed, size_t capacity_bytes)
+{
+    if (!c || !packed) return VOLYM_E_INVALID;
+    const size_t header = pack_header_bytes(c->shard_tiles);
+    if (capacity_bytes < header) return fail(c, VOLYM_E_INVALID, "volym_pack_shard: the buffer does not even hold the header (volym_packed_shard_bytes)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_pack_counters) {
+        HIPCHK(c, hipMalloc(&c->d_pack_counters, 4 * sizeof(uint32_t)));
+        HIPCHK(c, hipMemsetAsync(c->d_pack_counters, 0, 4 * sizeof(uint32_t), c->stream));
+    }
+    if (c->n_local == 0) return VOLYM_OK;
+    const uint32_t max_slots = static_cast<uint32_t>(std::min<size_t>((capacity_bytes - header) / 1024u, c->shard_tiles));
+    hipLaunchKernelGGL(volym_pack_shard_kernel, dim3(c->n_local), dim3(64), 0, c->stream, c->d_shard, static_cast<uint8_t*>(packed), c->n_local,
+                       c->shard_tiles, max_slots, c->d_pack_counters, c->pack_parity);
+    HIPCHK(c, hipGetLastError());
+    c->pack_parity ^= 1u;
+    return VOLYM_OK;
+}
+
+int volym_packed_tiles(volym_ctx* c, uint32_t* tiles_used, uint32_t* overflowed)
+{
+    if (!c || !tiles_used) return VOLYM_E_INVALID;
+    if (!c->d_pack_counters) return fail(c, VOLYM_E_STATE, "volym_packed_tiles: no volym_pack_shard yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t h[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(h, c->d_pack_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *tiles_used = h[c->pack_parity ^ 1u];        // the counter the last launch used
+    if (overflowed) *overflowed = h[2];
+    return VOLYM_OK;
+}
+
+int volym_assemble_packed(volym_ctx* c, const void* gathered, size_t stride_bytes)
+{
+    if (!c || !gathered) return VOLYM_E_INVALID;
+    if (stride_bytes < pack_header_bytes(c->shard_tiles)) return fail(c, VOLYM_E_INVALID, "volym_assemble_packed: stride smaller than the header");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(volym_assemble_packed_kernel, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint8_t*>(gathered), stride_bytes,
+                       c->d_frame, c->W, c->H, c->tiles_x, c->n_tiles, c->world, c->shard_tiles);
+    HIPCHK(c, hipGetLastError());
     return VOLYM_OK;
 }
 

@@ -424,4 +424,58 @@ __global__ __launch_bounds__(256) void volym_assemble_kernel(const uint32_t* __r
             gathered[(static_cast<size_t>(rank) * shard_tiles + local) * 256u + threadIdx.x];
 }
 
+// ---- packed shards: most tiles of a frame are constant, and a gather moves what is not ---------------------------------
+// A packed shard is [header: one uint2 per local tile, padded to 1 KiB][1 KiB tiles].  header[t] = {slot, 0} for a tile
+// stored at tiles[slot], or {PACK_CONSTANT, value} for a tile whose 256 pixels all equal `value` (not stored).  Slots are
+// handed out by an atomic counter: their order varies from launch to launch, the header says where each tile went.
+constexpr uint32_t PACK_CONSTANT = 0xffffffffu;
+__host__ __device__ inline size_t pack_header_bytes(uint32_t shard_tiles) { return (static_cast<size_t>(shard_tiles) * 8u + 1023u) & ~static_cast<size_t>(1023u); }
+
+// one wave per local tile; counters[parity] counts the slots of this launch, counters[parity ^ 1] is zeroed for the next
+// launch on the same stream, counters[2] collects an overflow flag (a tile that found no slot)
+__global__ __launch_bounds__(64) void volym_pack_shard_kernel(const uint32_t* __restrict__ shard, uint8_t* __restrict__ packed, uint32_t n_local,
+                                                              uint32_t shard_tiles, uint32_t max_slots, uint32_t* __restrict__ counters, uint32_t parity)
+{
+    const uint32_t t = blockIdx.x, lane = threadIdx.x;
+    if (t == 0u && lane == 0u) counters[parity ^ 1u] = 0u;
+    if (t >= n_local) return;
+    const uint4 px = reinterpret_cast<const uint4*>(shard + static_cast<size_t>(t) * 256u)[lane];
+    const uint32_t v0 = __builtin_amdgcn_readfirstlane(px.x);
+    const bool same = px.x == v0 && px.y == v0 && px.z == v0 && px.w == v0;
+    uint2* header = reinterpret_cast<uint2*>(packed);
+    if (__ballot(same) == ~0ull) {
+        if (lane == 0u) header[t] = make_uint2(PACK_CONSTANT, v0);
+        return;
+    }
+    uint32_t slot = 0;
+    if (lane == 0u) slot = atomicAdd(&counters[parity], 1u);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= max_slots) {                      // no room: the caller sized the buffer for another frame
+        if (lane == 0u) { counters[2] = 1u; header[t] = make_uint2(PACK_CONSTANT, 0u); }
+        return;
+    }
+    if (lane == 0u) header[t] = make_uint2(slot, 0u);
+    reinterpret_cast<uint4*>(packed + pack_header_bytes(shard_tiles) + static_cast<size_t>(slot) * 1024u)[lane] = px;
+}
+
+// root side: world packed shards, `stride` bytes apart, -> W x H raster (same pixel mapping as volym_assemble_kernel)
+__global__ __launch_bounds__(256) void volym_assemble_packed_kernel(const uint8_t* __restrict__ gathered, size_t stride, uint32_t* __restrict__ raster,
+                                                                    uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world,
+                                                                    uint32_t shard_tiles)
+{
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const uint32_t rank = tile % world, local = tile / world;
+    const uint8_t* base = gathered + static_cast<size_t>(rank) * stride;
+    const uint2 h = reinterpret_cast<const uint2*>(base)[local];
+    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t gx = tx * 16u + (((wave & 1u) << 3) | (lane & 7u)), gy = ty * 16u + (((wave >> 1) << 3) | (lane >> 3));
+    if (gx < W && gy < H) {
+        const uint32_t v = h.x == PACK_CONSTANT ? h.y
+                                                : reinterpret_cast<const uint32_t*>(base + pack_header_bytes(shard_tiles))[static_cast<size_t>(h.x) * 256u + threadIdx.x];
+        raster[static_cast<size_t>(gy) * W + gx] = v;
+    }
+}
+
 }  // namespace volym

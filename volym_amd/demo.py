@@ -124,6 +124,21 @@ class GpuContext:
     def assemble(self, gathered_device_ptr):
         self._ck(_lib.lib().volym_assemble(self.handle, C.c_void_p(gathered_device_ptr)))
 
+    def packed_shard_bytes(self, tiles):
+        return int(_lib.lib().volym_packed_shard_bytes(self.handle, int(tiles)))
+
+    def pack_shard(self, packed_device_ptr, capacity_bytes):
+        self._ck(_lib.lib().volym_pack_shard(self.handle, C.c_void_p(packed_device_ptr), int(capacity_bytes)))
+
+    def packed_tiles(self):
+        """(tiles stored by the last pack, overflow flag); synchronises."""
+        used, over = C.c_uint32(0), C.c_uint32(0)
+        self._ck(_lib.lib().volym_packed_tiles(self.handle, C.byref(used), C.byref(over)))
+        return int(used.value), int(over.value)
+
+    def assemble_packed(self, gathered_device_ptr, stride_bytes):
+        self._ck(_lib.lib().volym_assemble_packed(self.handle, C.c_void_p(gathered_device_ptr), int(stride_bytes)))
+
     def assemble_host(self, gathered):
         g = np.ascontiguousarray(gathered, np.uint8).ravel()
         self._ck(_lib.lib().volym_assemble_host(self.handle, scene._u8p(g)))
