@@ -53,40 +53,47 @@ def build_scene(args):
 
 
 def cpu_baseline(args, dims, volume, importances, lut, state, budget_s=12.0):
-    """The oracle (CPU restatement, NOT wgpu/lavapipe -- the reference cannot run here) timed on
-    the host cores over a bounded sample: every `stride`-th pixel row of the same frame."""
+    """The oracle (CPU restatement, NOT wgpu/lavapipe -- the reference cannot run here) timed on the host cores over
+    a bounded sample of the same frame: 16x16-pixel units (the reference's workgroup) handed to one pool of threads
+    that persists over the passes (oracle/volym_oracle.c vo_render_timed); median pass."""
     from oracle import oracle as O
     cam = O.CameraUniforms.from_buffer_copy(bytes(state.camera_uniforms()))
     par = O.Parameters.from_buffer_copy(bytes(state.parameter_uniforms()))
     W, H = args.width, args.height
     cores = os.cpu_count() or 1
     filt = 1 if args.linear else 0
-    # probe 8 rows around the centre to size the sample
-    t0 = time.perf_counter()
-    O.render(volume, importances, dims, lut, cam, par, W, H, filter=filt, threads=cores, rows=(H // 2 - 4, H // 2 + 4),
-             want_f32=False)
-    per_row = (time.perf_counter() - t0) / 8.0
-    rows_budget = max(8, int(budget_s / max(per_row, 1e-6)))
-    if rows_budget >= H:
-        passes = int(min(max(budget_s / max(per_row * H, 1e-6), 1), 20))     # whole frames until the budget is used
-        times = []
-        for _ in range(passes):
-            t0 = time.perf_counter()
-            _, _, k = O.render(volume, importances, dims, lut, cam, par, W, H, filter=filt, threads=cores, want_f32=False)
-            times.append(time.perf_counter() - t0)
-        dt = sorted(times)[len(times) // 2]
+    # probe: every 16th row, once, to size the sample
+    probe = list(range(0, H, 16))
+    secs, _ = O.render_timed(volume, importances, dims, lut, cam, par, W, H, 1, filter=filt, threads=cores, rowlist=probe)
+    per_row = float(secs[0]) / len(probe)
+    if per_row * H <= budget_s:
+        passes = int(min(max(budget_s / max(per_row * H, 1e-6), 3), 25))     # whole frames until the budget is used
+        secs, k = O.render_timed(volume, importances, dims, lut, cam, par, W, H, passes, filter=filt, threads=cores)
+        dt = float(np.median(secs))
         rays, sample = W * H, "full %dx%d frame, median of %d passes" % (W, H, passes)
     else:
-        stride = (H + rows_budget - 1) // rows_budget
+        stride = int(np.ceil(per_row * H / budget_s))
         rows = list(range(0, H, stride))
-        t0 = time.perf_counter()
-        k = None
-        for y in rows:
-            O.render(volume, importances, dims, lut, cam, par, W, H, filter=filt, threads=cores, rows=(y, y + 1), want_f32=False)
-        dt = time.perf_counter() - t0
-        rays, sample = W * len(rows), "every %d-th row of the %dx%d frame (%d rows)" % (stride, W, H, len(rows))
+        secs, k = O.render_timed(volume, importances, dims, lut, cam, par, W, H, 1, filter=filt, threads=cores, rowlist=rows)
+        dt = float(secs[0])
+        rays, sample = W * len(rows), "every %d-th row of the %dx%d frame (%d rows), one pass" % (stride, W, H, len(rows))
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": sample + "; CPU restatement (oracle/volym_oracle.c, gcc -O2), not wgpu/lavapipe"}, k
+            "sample": sample + "; 16x16-pixel units over a persistent pool of %d threads; CPU restatement (oracle/volym_oracle.c, gcc -O2), not wgpu/lavapipe" % cores}, k
+
+
+def frame_check(args, dims, volume, importances, lut, state, got_u8, n_rows=68):
+    """Untimed check of the frame the timed loop left behind (N = 1): `n_rows` sampled rows against the oracle,
+    rgba8 within 1 LSB.  Returns "ok" or a description of the mismatch."""
+    from oracle import oracle as O
+    cam = O.CameraUniforms.from_buffer_copy(bytes(state.camera_uniforms()))
+    par = O.Parameters.from_buffer_copy(bytes(state.parameter_uniforms()))
+    W, H = args.width, args.height
+    rows = sorted(set(int(round(y)) for y in np.linspace(0, H - 1, n_rows)))
+    _, ref, _ = O.render(volume, importances, dims, lut, cam, par, W, H, filter=1 if args.linear else 0, rowlist=rows, want_f32=False)
+    d = np.abs(got_u8[rows].astype(np.int32) - ref[rows].astype(np.int32))
+    if int(d.max()) <= 1:
+        return "ok"
+    return "MISMATCH: %d of %d sampled pixels differ from the oracle by more than 1 LSB (max %d)" % (int((d.max(axis=-1) > 1).sum()), len(rows) * W, int(d.max()))
 
 
 def main():
@@ -100,7 +107,7 @@ def main():
     ap.add_argument("--step", type=float, default=0.01)
     ap.add_argument("--layout", type=int, default=-1, help="volume layout: -1 by size (bricks beyond 64 MiB), 0 linear, 1 4x4x4 bricks")
     ap.add_argument("--kernel", type=int, default=2,
-                    help="0 direct (BASELINE configs[1]), 1 macro-cell, 2 persistent + LDS staging + shading queue (configs[2], default)")
+                    help="0 direct (BASELINE configs[1]), 1 macro-cell, 2 persistent workgroups + LDS-staged tables/distance field + shading queue (configs[2], default)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the driver's runs) or gloo (rehearsal on one device)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
     ap.add_argument("--frames-per-gather", type=int, default=4, help="N > 1, packed shards: frames batched into one collective")
@@ -111,6 +118,7 @@ def main():
     ap.add_argument("--cone", action="store_true")
     ap.add_argument("--xcd-bands", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frame-check", action="store_true", help="skip the untimed N = 1 check of the steady-state frame against the oracle")
     ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs[0..4] presets (default = c3, the configuration the metric is quoted on): "
                          "c1 teapot 512x512, c2 bonsai 1080p direct kernel, c3 bonsai 1080p, c4 bonsai 4K, c5 synthetic 1024^3 + labels 4K importance")
@@ -307,6 +315,30 @@ def main():
                 gather_check = "OVERFLOW"
         dist.barrier()
 
+    # ---- untimed self-check of the N = 1 path: the frame the timed loop left behind (a steady-state frame: cost-ordered
+    # work lists, super-fill stores, no float buffer) against a fresh context's first frame (bit-equal) and against the
+    # oracle on sampled rows (<= 1 LSB) -------------------------------------------------------------------------------
+    frame_check_result = None
+    if world == 1 and not args.no_frame_check:
+        torch.cuda.synchronize(dev)
+        got = frame.cpu().numpy().reshape(H, W, 4)
+        solo = demo.GpuContext(W, H, local_rank)
+        solo.set_option(_lib.OPT_KERNEL, args.kernel)
+        if args.layout >= 0:
+            solo.set_option(112, args.layout)
+        solo.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
+        solo.set_importances(importances, dims)
+        solo.set_transfer_function(lut)
+        solo.update(state.camera_uniforms(), state.parameter_uniforms())
+        solo.compute_pass()
+        solo.sync()
+        first = solo.read_rgba8()
+        solo.close()
+        if not np.array_equal(first, got):
+            frame_check_result = "MISMATCH: the steady-state frame differs from a fresh context's first frame in %d bytes" % int((first != got).sum())
+        else:
+            frame_check_result = frame_check(args, dims, volume, importances, lut, state, got)
+
     # ---- roofline of the dominant kernel: HIP events on the kernel's stream, algorithmic bytes from the
     # instrumented launch (reference fetch counts) -------------------------------------------------------
     n_ev = min(max(args.steps, 10), 500)
@@ -340,6 +372,7 @@ def main():
                 break
             except Exception:
                 pass
+    exit_code = 0
     if rank == 0:
         rays = W * H
         out = {
@@ -359,11 +392,12 @@ def main():
                 "workload": ("teapot 256x256x178->256^3" if args.teapot else "bonsai %d^3" % args.volume) + " uint8 @ %dx%d, %s filter, step %g, thr 0.15, opacity on%s, kernel=%s (BASELINE configs[%d])"
                             % (W, H, "linear" if args.linear else "nearest (reference parity)", args.step,
                                (", importance look-ahead %s" % ("cone" if args.cone else "straight") if args.importance else "") + (", gaussian smoothing" if args.gaussian else ""),
-                               {0: "direct", 1: "macro-cell", 2: "persistent+LDS-staged+queue"}[args.kernel], 1 if args.kernel == 0 else 2),
+                               {0: "direct", 1: "macro-cell", 2: "persistent workgroups, TF tables + distance field in LDS, shading queue, wave-ballot exit"}[args.kernel], 1 if args.kernel == 0 else 2),
                 "viewport": [W, H], "volume": list(dims), "tile_sharding": "interleaved 16x16 tiles, k %% %d" % world,
                 "gather": (None if world == 1 else ("packed shards: %d bytes per rank and frame (header + %d tiles that are not constant; a whole shard is %d bytes)" % (msg_bytes, packed_tiles, shard_bytes)) if packed_mode else ("whole shards: %d bytes per rank and frame" % shard_bytes)),
             },
             "gather_check": gather_check,
+            "frame_check": frame_check_result,
             "achieved_gbs": frame_bytes * args.steps / dt / 1e9,
             "b_alg_bytes_per_frame": frame_bytes,
             "b_alg_bytes_per_ray": frame_bytes / rays,
@@ -381,10 +415,20 @@ def main():
             out["cpu_baseline"] = cb
         else:
             out["cpu_baseline"] = None
+        failed = [c for c in (gather_check, frame_check_result) if c is not None and c != "ok"]
+        if failed:                       # a wrong frame is not a benchmark result
+            out["value"] = None
+            out["roofline"]["frac"] = None
+            out["error"] = "; ".join(failed)
         print(json.dumps(out))
+        exit_code = 1 if failed else 0
     ctx.close()
     if world > 1:
+        code = torch.tensor([exit_code], dtype=torch.int64, device=dev)
+        dist.broadcast(code, src=0)
+        exit_code = int(code.item())
         dist.destroy_process_group()
+    sys.exit(exit_code)
 
 
 if __name__ == "__main__":

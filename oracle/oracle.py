@@ -111,6 +111,16 @@ def lib():
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 f32p, u8p, C.POINTER(Counters)]
         L.vo_render.restype = C.c_int
+        L.vo_render_rowlist.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int,
+                                        C.POINTER(CameraUniforms), C.POINTER(Parameters),
+                                        C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                        f32p, u8p, C.POINTER(Counters)]
+        L.vo_render_rowlist.restype = C.c_int
+        L.vo_render_timed.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int,
+                                      C.POINTER(CameraUniforms), C.POINTER(Parameters),
+                                      C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                      C.c_int, C.POINTER(C.c_double), u8p, C.POINTER(Counters)]
+        L.vo_render_timed.restype = C.c_int
         L.vo_render_pixel.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int,
                                       C.POINTER(CameraUniforms), C.POINTER(Parameters),
                                       C.c_int, C.c_int, C.c_int, C.c_int, f32p,
@@ -199,8 +209,9 @@ def make_parameters(density_threshold=0.15, use_cone_importance_check=0, use_imp
 
 
 def render(volume, importances, dims, lut, cam_uniforms, params, W, H, filter=FILTER_NEAREST,
-           threads=None, rows=None, want_f32=True, want_u8=True):
-    """Returns (rgba_f32 [H,W,4] or None, rgba_u8 [H,W,4] or None, counters dict)."""
+           threads=None, rows=None, want_f32=True, want_u8=True, rowlist=None):
+    """Returns (rgba_f32 [H,W,4] or None, rgba_u8 [H,W,4] or None, counters dict).
+    rows = (y0, y1) renders that range, rowlist = [y, ...] those rows; other rows stay zero."""
     nx, ny, nz = dims
     volume = np.ascontiguousarray(volume, np.uint8).ravel()
     importances = np.ascontiguousarray(importances, np.uint8).ravel()
@@ -212,10 +223,41 @@ def render(volume, importances, dims, lut, cam_uniforms, params, W, H, filter=FI
     y0, y1 = rows if rows is not None else (0, H)
     if threads is None:
         threads = os.cpu_count() or 1
-    rc = lib().vo_render(_u8(volume), _u8(importances), nx, ny, nz, int(filter), _u8(lut),
-                         lut.size // 4, C.byref(cam_uniforms), C.byref(params), W, H, y0, y1,
-                         int(threads), _f32(f32) if want_f32 else None,
-                         _u8(u8) if want_u8 else None, C.byref(k))
+    if rowlist is not None:
+        rl = np.ascontiguousarray(rowlist, np.int32)
+        rc = lib().vo_render_rowlist(_u8(volume), _u8(importances), nx, ny, nz, int(filter), _u8(lut),
+                                     lut.size // 4, C.byref(cam_uniforms), C.byref(params), W, H,
+                                     rl.ctypes.data_as(C.POINTER(C.c_int)), int(rl.size),
+                                     int(threads), _f32(f32) if want_f32 else None,
+                                     _u8(u8) if want_u8 else None, C.byref(k))
+    else:
+        rc = lib().vo_render(_u8(volume), _u8(importances), nx, ny, nz, int(filter), _u8(lut),
+                             lut.size // 4, C.byref(cam_uniforms), C.byref(params), W, H, y0, y1,
+                             int(threads), _f32(f32) if want_f32 else None,
+                             _u8(u8) if want_u8 else None, C.byref(k))
     if rc != 0:
         raise ValueError("vo_render rejected its arguments")
     return f32, u8, k.as_dict()
+
+
+def render_timed(volume, importances, dims, lut, cam_uniforms, params, W, H, passes, filter=FILTER_NEAREST,
+                 threads=None, rowlist=None):
+    """CPU-baseline timing: one persistent pool of `threads` workers renders the frame (or `rowlist`) `passes`
+    times.  Returns (seconds per pass [passes], counters of one pass)."""
+    nx, ny, nz = dims
+    volume = np.ascontiguousarray(volume, np.uint8).ravel()
+    importances = np.ascontiguousarray(importances, np.uint8).ravel()
+    lut = np.ascontiguousarray(lut, np.uint8).ravel()
+    if threads is None:
+        threads = os.cpu_count() or 1
+    secs = np.zeros(int(passes), np.float64)
+    k = Counters()
+    rl = np.ascontiguousarray(rowlist, np.int32) if rowlist is not None else None
+    rc = lib().vo_render_timed(_u8(volume), _u8(importances), nx, ny, nz, int(filter), _u8(lut), lut.size // 4,
+                               C.byref(cam_uniforms), C.byref(params), W, H,
+                               rl.ctypes.data_as(C.POINTER(C.c_int)) if rl is not None else None,
+                               int(rl.size) if rl is not None else 0, int(threads), int(passes),
+                               secs.ctypes.data_as(C.POINTER(C.c_double)), None, C.byref(k))
+    if rc != 0:
+        raise ValueError("vo_render_timed failed (%d)" % rc)
+    return secs, k.as_dict()

@@ -14,8 +14,10 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------------- */
 /* Elementary functions (recipe in DESIGN.md "Elementary functions")          */
@@ -671,38 +673,141 @@ void vo_render_pixel(const uint8_t* volume, const uint8_t* importances, int nx, 
     if (counters) *counters = k;
 }
 
+/* Work distribution of vo_render / vo_render_rowlist: units of 16x16 pixels (the reference's workgroup,
+ * wgsl:213) handed out through one atomic ticket; every worker keeps its counters in
+ * a cache line of its own and they are summed after the join. */
 typedef struct {
     const vo_scene* s;
-    int y0, y1;
-    int* next_row;
-    pthread_mutex_t* mu;
+    int y0, y1;                 /* rows [y0, y1) (rowlist == NULL) */
+    const int* rowlist;         /* or: these rows, each as 16-pixel-wide units */
+    int n_rows;
+    int units_x, n_units;
+    int* ticket;                /* one ticket counter per pass */
+    int passes;                 /* the frame is rendered this many times (CPU-baseline timing); 1 otherwise */
+    pthread_barrier_t* bar;     /* passes > 1: between the passes */
+    double* pass_seconds;       /* passes > 1: wall time of every pass, written by worker 0 */
+    int worker;
+    int* go;                    /* passes > 1: 0 wait, 1 start, -1 give up (the pool could not be set up) */
     float* out_f32;
     uint8_t* out_u8;
     vo_counters k;
-} vo_job;
+    char pad[64];
+} __attribute__((aligned(64))) vo_job;
 
-static void* render_rows(void* arg)
+static void render_span(const vo_job* j, vo_counters* k, int y, int x0, int x1)
+{
+    const vo_scene* s = j->s;
+    for (int x = x0; x < x1; ++x) {
+        float px[4];
+        render_pixel(s, x, y, px, k);
+        size_t o = 4 * ((size_t)y * s->W + x);
+        if (j->out_f32) memcpy(j->out_f32 + o, px, sizeof px);
+        if (j->out_u8)
+            for (int c = 0; c < 4; ++c) j->out_u8[o + c] = to_unorm8(px[c]);
+    }
+}
+
+static void* render_units(void* arg)
 {
     vo_job* j = (vo_job*)arg;
     const vo_scene* s = j->s;
-    for (;;) {
-        pthread_mutex_lock(j->mu);
-        int y = *j->next_row;
-        *j->next_row = y + 4;
-        pthread_mutex_unlock(j->mu);
-        if (y >= j->y1) break;
-        int ye = y + 4 < j->y1 ? y + 4 : j->y1;
-        for (; y < ye; ++y)
-            for (int x = 0; x < s->W; ++x) {
-                float px[4];
-                render_pixel(s, x, y, px, &j->k);
-                size_t o = 4 * ((size_t)y * s->W + x);
-                if (j->out_f32) memcpy(j->out_f32 + o, px, sizeof px);
-                if (j->out_u8)
-                    for (int c = 0; c < 4; ++c) j->out_u8[o + c] = to_unorm8(px[c]);
-            }
+    vo_counters k = { 0, 0, 0, 0, 0 };     /* thread-local: no shared cache line inside the loop */
+    if (j->go && j->worker != 0) {
+        int g;
+        while ((g = __atomic_load_n(j->go, __ATOMIC_ACQUIRE)) == 0) sched_yield();
+        if (g < 0) return NULL;
     }
+    for (int pass = 0; pass < j->passes; ++pass) {
+        struct timespec t0, t1;
+        if (j->bar) {
+            pthread_barrier_wait(j->bar);
+            if (j->worker == 0) clock_gettime(CLOCK_MONOTONIC, &t0);
+        }
+        if (pass > 0) memset(&k, 0, sizeof k);                 /* counters describe one frame */
+        for (;;) {
+            const int u = __atomic_fetch_add(&j->ticket[pass], 1, __ATOMIC_RELAXED);
+            if (u >= j->n_units) break;
+            const int ux = u % j->units_x, uy = u / j->units_x;
+            const int x0 = ux * 16, x1 = x0 + 16 < s->W ? x0 + 16 : s->W;
+            if (j->rowlist) {
+                render_span(j, &k, j->rowlist[uy], x0, x1);
+            } else {
+                const int ya = j->y0 + uy * 16, yb = ya + 16 < j->y1 ? ya + 16 : j->y1;
+                for (int y = ya; y < yb; ++y) render_span(j, &k, y, x0, x1);
+            }
+        }
+        if (j->bar) {
+            pthread_barrier_wait(j->bar);
+            if (j->worker == 0) {
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                j->pass_seconds[pass] = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+            }
+        }
+    }
+    j->k = k;
     return NULL;
+}
+
+static int render_parallel(const vo_scene* s, int y0, int y1, const int* rowlist, int n_rows, int threads,
+                           float* out_f32, uint8_t* out_u8, vo_counters* counters, int passes, double* pass_seconds)
+{
+    if (passes < 1 || passes > 4096) return -1;
+    if (threads < 1) threads = 1;
+    if (threads > 512) threads = 512;
+    const int units_x = (s->W + 15) / 16;
+    const int units_y = rowlist ? n_rows : (y1 - y0 + 15) / 16;
+    const int n_units = units_x * (units_y > 0 ? units_y : 0);
+    if (threads > n_units) threads = n_units > 0 ? n_units : 1;
+    int* ticket = (int*)calloc((size_t)passes, sizeof(int));
+    if (!ticket) return -2;
+    vo_job* jobs = (vo_job*)aligned_alloc(64, sizeof(vo_job) * (size_t)threads);
+    pthread_t* tids = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+    if (!jobs || !tids) { free(jobs); free(tids); free(ticket); return -2; }
+    for (int i = 0; i < threads; ++i) {
+        memset(&jobs[i], 0, sizeof jobs[i]);
+        jobs[i].s = s; jobs[i].y0 = y0; jobs[i].y1 = y1; jobs[i].rowlist = rowlist; jobs[i].n_rows = n_rows;
+        jobs[i].units_x = units_x; jobs[i].n_units = n_units; jobs[i].ticket = ticket;
+        jobs[i].passes = passes; jobs[i].worker = i;
+        jobs[i].out_f32 = out_f32; jobs[i].out_u8 = out_u8;
+    }
+    int started = 0;
+    pthread_barrier_t bar;
+    int go = 0;
+    if (pass_seconds) {
+        /* the pool persists over the passes.  The barrier is sized by the workers that really exist: they are created
+         * first and wait for `go`; a pthread_create failure only makes the pool smaller. */
+        for (int i = 0; i < threads; ++i) { jobs[i].bar = &bar; jobs[i].pass_seconds = pass_seconds; jobs[i].go = &go; }
+        for (int i = 1; i < threads; ++i) {
+            if (pthread_create(&tids[started], NULL, render_units, &jobs[i]) != 0) break;
+            started++;
+        }
+        if (pthread_barrier_init(&bar, NULL, (unsigned)started + 1u) != 0) {
+            __atomic_store_n(&go, -1, __ATOMIC_RELEASE);      /* workers leave without marching */
+            for (int i = 0; i < started; ++i) pthread_join(tids[i], NULL);
+            free(jobs); free(tids); free(ticket);
+            return -2;
+        }
+        __atomic_store_n(&go, 1, __ATOMIC_RELEASE);
+    } else if (threads > 1) {
+        for (int i = 1; i < threads; ++i) {
+            /* a thread that cannot be created is not joined; the others (and this one) drain the ticket */
+            if (pthread_create(&tids[started], NULL, render_units, &jobs[i]) != 0) break;
+            started++;
+        }
+    }
+    render_units(&jobs[0]);
+    for (int i = 0; i < started; ++i) pthread_join(tids[i], NULL);
+    if (pass_seconds) pthread_barrier_destroy(&bar);
+    if (counters) {
+        memset(counters, 0, sizeof *counters);
+        for (int i = 0; i < threads; ++i) {
+            counters->n_vol += jobs[i].k.n_vol; counters->n_imp += jobs[i].k.n_imp;
+            counters->n_steps += jobs[i].k.n_steps; counters->n_dense += jobs[i].k.n_dense;
+            counters->n_hit += jobs[i].k.n_hit;
+        }
+    }
+    free(jobs); free(tids); free(ticket);
+    return 0;
 }
 
 int vo_render(const uint8_t* volume, const uint8_t* importances, int nx, int ny, int nz,
@@ -714,32 +819,33 @@ int vo_render(const uint8_t* volume, const uint8_t* importances, int nx, int ny,
     if (nx <= 0 || ny <= 0 || nz <= 0 || W <= 0 || H <= 0 || tf_n <= 0) return -1;
     if (y0 < 0) y0 = 0;
     if (y1 > H) y1 = H;
-    if (threads < 1) threads = 1;
-    if (threads > 256) threads = 256;
     vo_scene s;
     scene_init(&s, volume, importances, nx, ny, nz, filter, tf_lut, tf_n, cam, par, W, H);
+    return render_parallel(&s, y0, y1, NULL, 0, threads, out_f32, out_u8, counters, 1, NULL);
+}
 
-    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
-    int next_row = y0;
-    vo_job jobs[256];
-    pthread_t tids[256];
-    for (int i = 0; i < threads; ++i) {
-        jobs[i].s = &s; jobs[i].y0 = y0; jobs[i].y1 = y1; jobs[i].next_row = &next_row;
-        jobs[i].mu = &mu; jobs[i].out_f32 = out_f32; jobs[i].out_u8 = out_u8;
-        memset(&jobs[i].k, 0, sizeof jobs[i].k);
-    }
-    if (threads == 1) render_rows(&jobs[0]);
-    else {
-        for (int i = 0; i < threads; ++i) pthread_create(&tids[i], NULL, render_rows, &jobs[i]);
-        for (int i = 0; i < threads; ++i) pthread_join(tids[i], NULL);
-    }
-    if (counters) {
-        memset(counters, 0, sizeof *counters);
-        for (int i = 0; i < threads; ++i) {
-            counters->n_vol += jobs[i].k.n_vol; counters->n_imp += jobs[i].k.n_imp;
-            counters->n_steps += jobs[i].k.n_steps; counters->n_dense += jobs[i].k.n_dense;
-            counters->n_hit += jobs[i].k.n_hit;
-        }
-    }
-    return 0;
+int vo_render_rowlist(const uint8_t* volume, const uint8_t* importances, int nx, int ny, int nz,
+                      int filter, const uint8_t* tf_lut, int tf_n, const vo_camera_uniforms* cam,
+                      const vo_parameters* par, int W, int H, const int* rows, int n_rows, int threads,
+                      float* out_f32, uint8_t* out_u8, vo_counters* counters)
+{
+    if (!volume || !importances || !tf_lut || !cam || !par || !rows) return -1;
+    if (nx <= 0 || ny <= 0 || nz <= 0 || W <= 0 || H <= 0 || tf_n <= 0 || n_rows < 0) return -1;
+    for (int i = 0; i < n_rows; ++i) if (rows[i] < 0 || rows[i] >= H) return -1;
+    vo_scene s;
+    scene_init(&s, volume, importances, nx, ny, nz, filter, tf_lut, tf_n, cam, par, W, H);
+    return render_parallel(&s, 0, 0, rows, n_rows, threads, out_f32, out_u8, counters, 1, NULL);
+}
+
+int vo_render_timed(const uint8_t* volume, const uint8_t* importances, int nx, int ny, int nz,
+                    int filter, const uint8_t* tf_lut, int tf_n, const vo_camera_uniforms* cam,
+                    const vo_parameters* par, int W, int H, const int* rows, int n_rows, int threads,
+                    int passes, double* pass_seconds, uint8_t* out_u8, vo_counters* counters)
+{
+    if (!volume || !importances || !tf_lut || !cam || !par || !pass_seconds) return -1;
+    if (nx <= 0 || ny <= 0 || nz <= 0 || W <= 0 || H <= 0 || tf_n <= 0 || n_rows < 0) return -1;
+    for (int i = 0; rows && i < n_rows; ++i) if (rows[i] < 0 || rows[i] >= H) return -1;
+    vo_scene s;
+    scene_init(&s, volume, importances, nx, ny, nz, filter, tf_lut, tf_n, cam, par, W, H);
+    return render_parallel(&s, 0, rows ? 0 : H, rows, rows ? n_rows : 0, threads, NULL, out_u8, counters, passes, pass_seconds);
 }

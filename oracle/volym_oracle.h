@@ -108,12 +108,29 @@ void vo_map_segments(uint8_t* data, size_t len, const uint8_t* label_values,
  * Renders pixel rows [y0, y1) of a W x H frame.  out_f32 (may be NULL): W*H*4
  * floats, pre-quantisation (C.rgb, alpha).  out_u8 (may be NULL): W*H*4 bytes as
  * an rgba8unorm store would leave them.  Rows outside [y0,y1) are untouched.
- * `threads` > 1 splits the rows over pthreads.  counters may be NULL. */
+ * `threads` > 1 hands 16x16-pixel units (the reference's workgroup, wgsl:213) to that many pthreads.
+ * counters may be NULL.  Returns 0, -1 on bad arguments, -2 when out of memory. */
 int vo_render(const uint8_t* volume, const uint8_t* importances, int nx, int ny, int nz,
               int filter, const uint8_t* tf_lut, int tf_n,
               const vo_camera_uniforms* cam, const vo_parameters* par,
               int W, int H, int y0, int y1, int threads,
               float* out_f32, uint8_t* out_u8, vo_counters* counters);
+
+/* The same for a list of rows (each row in [0, H); handed out as 16-pixel spans): sampled checks of large frames. */
+int vo_render_rowlist(const uint8_t* volume, const uint8_t* importances, int nx, int ny, int nz,
+                      int filter, const uint8_t* tf_lut, int tf_n,
+                      const vo_camera_uniforms* cam, const vo_parameters* par,
+                      int W, int H, const int* rows, int n_rows, int threads,
+                      float* out_f32, uint8_t* out_u8, vo_counters* counters);
+
+/* CPU-baseline timing (bench.py): the frame (rows == NULL) or the listed rows rendered `passes` times by ONE pool of
+ * `threads` workers that persists over the passes; pass_seconds[passes] receives the wall time of every pass
+ * (barrier to barrier, CLOCK_MONOTONIC).  Counters describe one pass. */
+int vo_render_timed(const uint8_t* volume, const uint8_t* importances, int nx, int ny, int nz,
+                    int filter, const uint8_t* tf_lut, int tf_n,
+                    const vo_camera_uniforms* cam, const vo_parameters* par,
+                    int W, int H, const int* rows, int n_rows, int threads,
+                    int passes, double* pass_seconds, uint8_t* out_u8, vo_counters* counters);
 
 /* one pixel, for spot checks */
 void vo_render_pixel(const uint8_t* volume, const uint8_t* importances, int nx, int ny, int nz,

@@ -1,0 +1,194 @@
+// VALU issue rate on gfx950 by waves per SIMD (development aid).  One workgroup per CU of T threads (T / 256 waves per
+// SIMD), every wave runs REPS iterations of 64 independent instructions of one kind; prints SIMD cycles per
+// wave-instruction (s_memtime, max over the waves of a CU) and wall-clock instructions per ns.
+//   hipcc --offload-arch=gfx950 -O2 valu_rate.hip -o valu_rate && ./valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define REPS 2000
+
+#define BODY8(OP)                                                              \
+    asm volatile(OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)               \
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) \
+                 : "v"(x), "v"(y), "s"(sc));
+
+#define OP_FMA(i) "v_fma_f32 %" #i ", %8, %9, %" #i "\n"
+#define OP_MUL(i) "v_mul_f32 %" #i ", %" #i ", %8\n"
+#define OP_ADD(i) "v_add_f32 %" #i ", %" #i ", %9\n"
+#define OP_FLR(i) "v_cvt_flr_i32_f32 %" #i ", %" #i "\n"
+#define OP_MED(i) "v_med3_i32 %" #i ", %" #i ", 0, %9\n"
+#define OP_MAD24(i) "v_mad_u32_u24 %" #i ", %" #i ", %10, %8\n"
+#define OP_CND(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define OP_RCP(i) "v_rcp_f32 %" #i ", %" #i "\n"
+#define OP_DPP(i) "v_mov_b32_dpp %" #i ", %" #i " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define OP_AND(i) "v_and_b32 %" #i ", %" #i ", %8\n"
+#define OP_CMP(i) "v_cmp_lt_f32 vcc, %" #i ", %8\n"
+#define OP_RDL(i) "v_readlane_b32 s20, %" #i ", 3\n"
+#define OP_MOV(i) "v_mov_b32 %" #i ", %8\n"
+#define OP_CND64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[20:21]\n"
+#define OP_CNDMIX(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\nv_fma_f32 %" #i ", %8, %9, %" #i "\n"
+#define OP_CNDMIX3(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\nv_fma_f32 %" #i ", %8, %9, %" #i "\nv_mul_f32 %" #i ", %" #i ", %8\nv_add_f32 %" #i ", %" #i ", %9\n"
+#define OP_ADDS(i) "v_add_f32 %" #i ", %10, %" #i "\n"
+#define OP_CMP64(i) "v_cmp_lt_f32_e64 s[20:21], %" #i ", %8\n"
+#define OP_ADDU(i) "v_add_u32 %" #i ", %" #i ", %8\n"
+#define OP_LSH(i) "v_lshlrev_b32 %" #i ", 3, %" #i "\n"
+#define OP_MULLIT(i) "v_mul_f32 %" #i ", 0x3f8ccccd, %" #i "\n"
+#define OP_MAX(i) "v_max_f32 %" #i ", %" #i ", %8\n"
+#define OP_MIN3(i) "v_min3_f32 %" #i ", %" #i ", %8, %9\n"
+#define OP_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
+#define OP_BFE(i) "v_bfe_u32 %" #i ", %" #i ", 3, 5\n"
+#define OP_CVTU(i) "v_cvt_f32_u32 %" #i ", %" #i "\n"
+#define OP_FMIX(i) "v_fma_f32 %" #i ", %8, %9, %" #i "\nv_cvt_flr_i32_f32 %" #i ", %" #i "\n"
+
+template <int KIND>
+__global__ __launch_bounds__(1024) void rate_kernel(uint32_t* out, float x, float y, uint32_t sc)
+{
+    float a[8];
+    for (int i = 0; i < 8; ++i) a[i] = x * (float)(threadIdx.x + i);
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < REPS; ++r) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (KIND == 0) BODY8(OP_FMA)
+            if (KIND == 1) BODY8(OP_MUL)
+            if (KIND == 2) BODY8(OP_FLR)
+            if (KIND == 3) BODY8(OP_MED)
+            if (KIND == 4) BODY8(OP_MAD24)
+            if (KIND == 5) BODY8(OP_CND)
+            if (KIND == 6) BODY8(OP_RCP)
+            if (KIND == 7) BODY8(OP_DPP)
+            if (KIND == 8) BODY8(OP_CMP)
+            if (KIND == 9) { asm volatile(OP_RDL(0) OP_RDL(1) OP_RDL(2) OP_RDL(3) OP_RDL(4) OP_RDL(5) OP_RDL(6) OP_RDL(7)
+                                          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                                          : "v"(x), "v"(y), "s"(sc) : "s20"); }
+            if (KIND == 10) BODY8(OP_ADD)
+            if (KIND == 11) { asm volatile(OP_CND64(0) OP_CND64(1) OP_CND64(2) OP_CND64(3) OP_CND64(4) OP_CND64(5) OP_CND64(6) OP_CND64(7)
+                                          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                                          : "v"(x), "v"(y), "s"(sc) : "s20", "s21"); }
+            if (KIND == 12) BODY8(OP_CNDMIX)
+            if (KIND == 13) BODY8(OP_CNDMIX3)
+            if (KIND == 14) BODY8(OP_ADDS)
+            if (KIND == 15) { asm volatile(OP_CMP64(0) OP_CMP64(1) OP_CMP64(2) OP_CMP64(3) OP_CMP64(4) OP_CMP64(5) OP_CMP64(6) OP_CMP64(7)
+                                          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                                          : "v"(x), "v"(y), "s"(sc) : "s20", "s21"); }
+            if (KIND == 16) BODY8(OP_ADDU)
+            if (KIND == 17) BODY8(OP_LSH)
+            if (KIND == 18) BODY8(OP_MULLIT)
+            if (KIND == 19) BODY8(OP_MAX)
+            if (KIND == 20) BODY8(OP_MIN3)
+            if (KIND == 21) BODY8(OP_MULLO)
+            if (KIND == 22) BODY8(OP_BFE)
+            if (KIND == 23) BODY8(OP_CVTU)
+            if (KIND == 24) BODY8(OP_FMIX)
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += a[i];
+    if (s == 12345.678f) out[0] = 1;
+    if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * 16 + (threadIdx.x >> 6)] = (uint32_t)(t1 - t0);
+}
+
+// packed f32: two floats per lane per instruction
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int KIND>
+__global__ __launch_bounds__(1024) void rate_pk_kernel(uint32_t* out, float x, float y)
+{
+    f32x2 a[8];
+    const f32x2 xx = {x, y}, yy = {y, x};
+    for (int i = 0; i < 8; ++i) a[i] = xx * (float)(threadIdx.x + i);
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < REPS; ++r) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (KIND == 0) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(xx));
+                if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(xx), "v"(yy));
+                if (KIND == 2) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(yy));
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    f32x2 s = {0, 0};
+    for (int i = 0; i < 8; ++i) s += a[i];
+    if (s.x + s.y == 12345.678f) out[0] = 1;
+    if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * 16 + (threadIdx.x >> 6)] = (uint32_t)(t1 - t0);
+}
+
+template <class F>
+static void run(const char* name, F launch, uint32_t* d_out, int n_cus)
+{
+    const int threads_list[4] = {256, 512, 768, 1024};
+    for (int ti = 0; ti < 4; ++ti) {
+        const int T = threads_list[ti];
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        launch(n_cus, T);                                   // warm-up
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0, 0);
+        launch(n_cus, T);
+        (void)hipEventRecord(e1, 0);
+        (void)hipDeviceSynchronize();
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        std::vector<uint32_t> h(1 + n_cus * 16);
+        (void)hipMemcpy(h.data(), d_out, h.size() * 4, hipMemcpyDeviceToHost);
+        const int waves = T / 64;
+        double sum = 0; uint32_t mx = 0;
+        for (int b = 0; b < n_cus; ++b) for (int w = 0; w < waves; ++w) { sum += h[1 + b * 16 + w]; if (h[1 + b * 16 + w] > mx) mx = h[1 + b * 16 + w]; }
+        const double per_wave_instr = 64.0 * REPS;
+        const double mean_cycles = sum / (n_cus * waves);
+        // SIMD cycles per wave-instruction = mean wave time / (instructions of the waves sharing the SIMD)
+        std::printf("%-14s %4d threads (%d waves/SIMD): %.2f cycles per instr per SIMD (wave: %.2f cyc/instr), wall %.3f ms -> %.1f Ginstr/s chip\n", name, T, waves / 4,
+                    mean_cycles / (per_wave_instr * (waves / 4)), mean_cycles / per_wave_instr, ms, n_cus * waves * per_wave_instr / (ms * 1e6));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+}
+
+int main()
+{
+    hipDeviceProp_t prop;
+    (void)hipGetDeviceProperties(&prop, 0);
+    const int n_cus = prop.multiProcessorCount;
+    uint32_t* d_out = nullptr;
+    (void)hipMalloc(&d_out, (1 + n_cus * 16) * 4);
+    (void)hipMemset(d_out, 0, (1 + n_cus * 16) * 4);
+    std::printf("device %s, %d CUs, clock %d kHz\n", prop.gcnArchName, n_cus, prop.clockRate);
+#define RUN(NAME, K) run(NAME, [&](int g, int T) { hipLaunchKernelGGL(rate_kernel<K>, dim3(g), dim3(T), 0, 0, d_out, 1.0001f, 0.5f, 3u); }, d_out, n_cus)
+    RUN("v_fma_f32", 0);
+    RUN("v_mul_f32", 1);
+    RUN("v_add_f32", 10);
+    RUN("v_cvt_flr", 2);
+    RUN("v_med3_i32", 3);
+    RUN("v_mad_u32_u24", 4);
+    RUN("v_cndmask", 5);
+    RUN("v_rcp_f32", 6);
+    RUN("v_mov_dpp", 7);
+    RUN("v_cmp_lt_f32", 8);
+    RUN("v_readlane", 9);
+    RUN("cndmask_e64_sgpr", 11);
+    RUN("cnd+fma (x2)", 12);
+    RUN("cnd+3 (x4)", 13);
+    RUN("v_add_f32 sgpr", 14);
+    RUN("v_cmp_e64 sgpr", 15);
+    RUN("v_add_u32", 16);
+    RUN("v_lshlrev", 17);
+    RUN("v_mul literal", 18);
+    RUN("v_max_f32", 19);
+    RUN("v_min3_f32", 20);
+    RUN("v_mul_lo_u32", 21);
+    RUN("v_bfe_u32", 22);
+    RUN("v_cvt_f32_u32", 23);
+    RUN("fma+flr (x2)", 24);
+#define RUNPK(NAME, K) run(NAME, [&](int g, int T) { hipLaunchKernelGGL(rate_pk_kernel<K>, dim3(g), dim3(T), 0, 0, d_out, 1.0001f, 0.5f); }, d_out, n_cus)
+    RUNPK("v_pk_mul_f32", 0);
+    RUNPK("v_pk_fma_f32", 1);
+    RUNPK("v_pk_add_f32", 2);
+    (void)hipFree(d_out);
+    return 0;
+}

@@ -1,0 +1,235 @@
+"""Parity of the paths bench.py actually times, and of BASELINE.json configs[3] and configs[4].
+
+* the timed path: raster output WITHOUT the float side buffer, a static view rendered three times (frame 1
+  measures costs, frames 2+ run the cost-ordered work lists: depth-parallel quarter items, 16x16 super-fill
+  items with their 16-byte stores) -- rgba8 against the oracle, <= 1 LSB;
+* configs[3]: bonsai 256^3 @ 3840x2160, sampled rows against the oracle, and 8 virtual ranks through the PACKED
+  shard protocol bit-equal to the frame one context renders alone;
+* configs[4]: synth_bonsai(1024) + labels @ 3840x2160, importance rendering, straight look-ahead 15 (whole frame:
+  pixels of sampled rows + the reference-fetch counters of the full frame) and cone (sampled rows), on the
+  auto-bricked layout.
+
+The fetch counters come from the instrumented instantiation (general flag handling, unculled, no depth-parallel
+items); the production instantiations are pinned by their pixels.  Parity itself is unpinned against the reference
+(oracle/volym_oracle.h).
+"""
+import numpy as np
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _uniforms(oracle, W, H, pose=(0.0, 0.0, 0.0), **kw):
+    from volym_amd import _lib
+    cam = oracle.benchmark_camera_uniforms(W / H, *pose)
+    par = oracle.make_parameters(**kw)
+    return (cam, par, _lib.CameraUniforms.from_buffer_copy(bytes(cam)), _lib.ParameterUniforms.from_buffer_copy(bytes(par)))
+
+
+def _u8_close(got, ref, label):
+    d = int(np.abs(got.astype(np.int32) - ref.astype(np.int32)).max()) if got.size else 0
+    assert d <= 1, "%s: rgba8 differs by %d (%d bytes differ)" % (label, d, int((got != ref).sum()))
+
+
+@pytest.mark.parametrize("size", [(192, 112), (256, 144), (64, 64)], ids=lambda s: "%dx%d" % s)
+@pytest.mark.parametrize("kw", [dict(), dict(use_importance_rendering=1, importance_check_ahead_steps=6), dict(use_gaussian_smoothing=1)],
+                         ids=["base", "importance", "smoothed"])
+def test_timed_path_small(oracle, volym_lib, size, kw):
+    """W % 4 == 0, no float buffer, three frames of a static view: every frame equals frame 1 and the oracle."""
+    from volym_amd import demo, scene
+    W, H = size
+    raw, labels = common.bonsai(64)
+    dims = (64, 64, 64)
+    vol, imp = common.oracle_scene(oracle, raw, labels, common.BONSAI_SEGMENTS, dims)
+    for pose in ((0.0, 0.0, 0.0), (30.0, -20.0, 2.5)):        # the second: a small cube, most tiles are fills
+        cam, par, cu, pu = _uniforms(oracle, W, H, pose, **kw)
+        _, ref_u8, _ = oracle.render(vol, imp, dims, oracle.tf_default_lut(), cam, par, W, H, want_f32=False)
+        with demo.GpuContext(W, H, 0) as ctx:                  # default options: WRITE_F32 off, kernel 2, feedback on
+            ctx.set_volume(scene.prepare_volume(raw, dims, True), dims, 0)
+            ctx.set_importances(scene.prepare_volume(scene.map_segments_to_importance(labels, common.BONSAI_SEGMENTS), dims, True), dims)
+            ctx.set_transfer_function(scene.default_lut())
+            ctx.update(cu, pu)
+            frames = []
+            for _ in range(4):
+                ctx.compute_pass()
+                ctx.sync()
+                frames.append(ctx.read_rgba8())
+        for i, f in enumerate(frames):
+            assert np.array_equal(f, frames[0]), (pose, kw, i)
+            _u8_close(f, ref_u8, "frame %d pose %s %s" % (i, pose, kw))
+
+
+def test_timed_path_bench_workload(oracle, volym_lib):
+    """The bench workload itself (bonsai 256^3 @ 1920x1080, benchmark parameters), as bench.py runs it: raster output,
+    no float buffer, back-to-back frames of a static view.  Frames 1..5 are identical and every 8th row equals the oracle."""
+    from volym_amd import demo, scene
+    raw, labels = common.bonsai(256)
+    dims = (256, 256, 256)
+    W, H = 1920, 1080
+    cam, par, cu, pu = _uniforms(oracle, W, H)
+    vol_o, imp_o = common.oracle_scene(oracle, raw, labels, common.BONSAI_SEGMENTS, dims)
+    rows = list(range(0, H, 8))
+    _, ref_u8, _ = oracle.render(vol_o, imp_o, dims, oracle.tf_default_lut(), cam, par, W, H, rowlist=rows, want_f32=False)
+    with demo.GpuContext(W, H, 0) as ctx:
+        ctx.set_volume(scene.prepare_volume(raw, dims, True), dims, 0)
+        ctx.set_importances(scene.prepare_volume(scene.map_segments_to_importance(labels, common.BONSAI_SEGMENTS), dims, True), dims)
+        ctx.set_transfer_function(scene.default_lut())
+        ctx.update(cu, pu)
+        frames = []
+        for _ in range(5):
+            ctx.compute_pass()                                  # no sync in between: the cost feedback must cope
+            frames.append(None)
+        ctx.sync()
+        last = ctx.read_rgba8()
+        ctx.update(cu, pu)                                      # an identical update keeps the view "static"
+        for i in range(3):
+            ctx.compute_pass()
+            ctx.sync()
+            f = ctx.read_rgba8()
+            assert np.array_equal(f, last), i
+    with demo.GpuContext(W, H, 0) as fresh:                     # first frame of a fresh context: centre-first list, no fills
+        fresh.set_volume(scene.prepare_volume(raw, dims, True), dims, 0)
+        fresh.set_importances(np.zeros(256 ** 3, np.uint8), dims)
+        fresh.set_transfer_function(scene.default_lut())
+        fresh.update(cu, pu)
+        fresh.compute_pass()
+        fresh.sync()
+        assert np.array_equal(fresh.read_rgba8(), last)
+    _u8_close(last[rows], ref_u8[rows], "bench workload, steady-state frame")
+
+
+def test_config3_4k(oracle, volym_lib):
+    """BASELINE configs[3]: bonsai 256^3 @ 3840x2160.  One context: floats of 68 sampled rows against the oracle and the
+    counters of the full frame; the steady-state frame without the float buffer equal to it; 8 virtual ranks through
+    the packed protocol (volym_pack_shard / volym_assemble_packed) bit-equal to the solo frame."""
+    from volym_amd import _lib, demo, scene
+    raw, labels = common.bonsai(256)
+    dims = (256, 256, 256)
+    W, H = 3840, 2160
+    cam, par, cu, pu = _uniforms(oracle, W, H)
+    vol_o, imp_o = common.oracle_scene(oracle, raw, labels, common.BONSAI_SEGMENTS, dims)
+    volume = scene.prepare_volume(raw, dims, True)
+    importances = scene.prepare_volume(scene.map_segments_to_importance(labels, common.BONSAI_SEGMENTS), dims, True)
+    lut = scene.default_lut()
+    rows = list(range(5, H, 32))
+    ref_f32, ref_u8, _ = oracle.render(vol_o, imp_o, dims, oracle.tf_default_lut(), cam, par, W, H, rowlist=rows)
+    _, _, ref_k = oracle.render(vol_o, imp_o, dims, oracle.tf_default_lut(), cam, par, W, H, want_f32=False, want_u8=False)
+
+    def make(rank, world, f32):
+        c = demo.GpuContext(W, H, 0)
+        if f32:
+            c.set_option(_lib.OPT_WRITE_F32, 1)
+        c.set_shard(rank, world)
+        c.set_volume(volume, dims, 0)
+        c.set_importances(importances, dims)
+        c.set_transfer_function(lut)
+        c.update(cu, pu)
+        return c
+
+    with make(0, 1, True) as ctx:
+        ctx.compute_pass()
+        ctx.sync()
+        f32, u8 = ctx.read_rgba32f(), ctx.read_rgba8()
+        k = ctx.stats_pass()
+    for key in ("n_vol", "n_imp", "n_steps", "n_dense", "n_hit"):
+        assert k[key] == ref_k[key], (key, k[key], ref_k[key])
+    err, over, du8, _ = common.compare_images(f32[rows], u8[rows], ref_f32[rows], ref_u8[rows], TOL)
+    assert over == 0 and err <= TOL and du8 <= 1, (err, over, du8)
+    with make(0, 1, False) as ctx:
+        for _ in range(4):
+            ctx.compute_pass()
+        ctx.sync()
+        assert np.array_equal(ctx.read_rgba8(), u8)
+    world = 8
+    with demo.GpuContext(4096, 4096, 0) as scratch:            # 64 MiB of device memory for the packed shards
+        mem, mem_bytes = scratch.frame_device_ptr(), 4096 * 4096 * 4
+        ctxs = [make(r, world, False) for r in range(world)]
+        try:
+            cap = ctxs[0].packed_shard_bytes(1 << 30)
+            assert world * cap <= mem_bytes
+            used = []
+            for r, c in enumerate(ctxs):
+                c.compute_pass()
+                c.pack_shard(mem + r * cap, cap)
+                u, over_flag = c.packed_tiles()
+                assert over_flag == 0
+                used.append(u)
+            stride = ctxs[0].packed_shard_bytes(max(used))
+            for frame in range(3):
+                for r, c in enumerate(ctxs):
+                    c.compute_pass()
+                    c.pack_shard(mem + r * stride, stride)
+                    assert c.packed_tiles() == (used[r], 0)
+                ctxs[0].assemble_packed(mem, stride)
+                ctxs[0].sync()
+                assert np.array_equal(ctxs[0].read_rgba8(), u8), frame
+        finally:
+            for c in ctxs:
+                c.close()
+
+
+@pytest.fixture(scope="module")
+def bonsai1024():
+    from volym_amd import scene
+    raw, labels = common.bonsai(1024)
+    dims = (1024, 1024, 1024)
+    volume = scene.prepare_volume(raw, dims, True)
+    importances = scene.prepare_volume(scene.map_segments_to_importance(labels, common.BONSAI_SEGMENTS), dims, True)
+    common._cache.pop(("bonsai", 1024), None)                 # 2 GiB of raw input are not needed again
+    return dims, volume, importances
+
+
+def test_config4_1024cube_labels_4k(oracle, volym_lib, bonsai1024):
+    """BASELINE configs[4]: synthetic 1024^3 volume + label map @ 3840x2160, importance rendering.  The library bricks
+    volumes of this size on upload (4x4x4 bricks) and runs the importance-rendering instantiation.  Straight look-ahead
+    15: 68 sampled rows (floats, <= 1e-4) and the reference-fetch counters of the whole frame; the steady-state frames
+    (cost-ordered lists, no float buffer) equal to the first; cone look-ahead: 17 sampled rows."""
+    from volym_amd import _lib, demo, scene
+    dims, volume, importances = bonsai1024
+    W, H = 3840, 2160
+    lut = scene.default_lut()
+    lut_o = oracle.tf_default_lut()
+    with demo.GpuContext(W, H, 0) as ctx:
+        ctx.set_option(_lib.OPT_WRITE_F32, 1)
+        ctx.set_volume(volume, dims, 0)
+        ctx.set_importances(importances, dims)
+        ctx.set_transfer_function(lut)
+        for kw, rows, whole in ((dict(use_importance_rendering=1, importance_check_ahead_steps=15), list(range(3, H, 32)), True),
+                                (dict(use_importance_rendering=1, importance_check_ahead_steps=15, use_cone_importance_check=1), list(range(40, H, 128)), False),
+                                (dict(), list(range(17, H, 64)), False)):
+            cam, par, cu, pu = _uniforms(oracle, W, H, **kw)
+            ref_f32, ref_u8, k_rows = oracle.render(volume, importances, dims, lut_o, cam, par, W, H, rowlist=rows)
+            ctx.update(cu, pu)
+            ctx.compute_pass()
+            ctx.sync()
+            f32, u8 = ctx.read_rgba32f(), ctx.read_rgba8()
+            err, over, du8, _ = common.compare_images(f32[rows], u8[rows], ref_f32[rows], ref_u8[rows], TOL)
+            assert over == 0 and err <= TOL and du8 <= 1, (kw, err, over, du8)
+            assert u8[rows][..., :3].any(), "the sampled rows must see the object"
+            for _ in range(3):                                  # the cost-ordered frames of the static view
+                ctx.compute_pass()
+            ctx.sync()
+            assert np.array_equal(ctx.read_rgba8(), u8), kw
+            assert np.array_equal(ctx.read_rgba32f().view(np.uint32), f32.view(np.uint32)), kw
+            if whole:
+                _, _, ref_k = oracle.render(volume, importances, dims, lut_o, cam, par, W, H, want_f32=False, want_u8=False)
+                k = ctx.stats_pass()
+                for key in ("n_vol", "n_imp", "n_steps", "n_dense", "n_hit"):
+                    assert k[key] == ref_k[key], (kw, key, k[key], ref_k[key])
+    # the timed form of the straight look-ahead: no float buffer
+    cam, par, cu, pu = _uniforms(oracle, W, H, use_importance_rendering=1, importance_check_ahead_steps=15)
+    rows = list(range(3, H, 32))
+    _, ref_u8, _ = oracle.render(volume, importances, dims, lut_o, cam, par, W, H, rowlist=rows, want_f32=False)
+    with demo.GpuContext(W, H, 0) as ctx:
+        ctx.set_volume(volume, dims, 0)
+        ctx.set_importances(importances, dims)
+        ctx.set_transfer_function(lut)
+        ctx.update(cu, pu)
+        for _ in range(4):
+            ctx.compute_pass()
+        ctx.sync()
+        _u8_close(ctx.read_rgba8()[rows], ref_u8[rows], "configs[4], steady state")
