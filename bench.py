@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--cone", action="store_true")
     ap.add_argument("--xcd-bands", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-moving-view", action="store_true", help="skip the first-frame and turntable timings (N = 1)")
+    ap.add_argument("--turntable-frames", type=int, default=720)
+    ap.add_argument("--turntable-degrees", type=float, default=0.25, help="rotation between consecutive views of the turntable")
     ap.add_argument("--no-frame-check", action="store_true", help="skip the untimed N = 1 check of the steady-state frame against the oracle")
     ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs[0..4] presets (default = c3, the configuration the metric is quoted on): "
@@ -164,7 +167,7 @@ def main():
     ctx = demo.GpuContext(W, H, local_rank)
     ctx.set_option(_lib.OPT_KERNEL, args.kernel)
     if args.layout >= 0:
-        ctx.set_option(112, args.layout)
+        ctx.set_option(_lib.OPT_VOLUME_LAYOUT, args.layout)
     if args.xcd_bands >= 0:
         ctx.set_option(_lib.OPT_XCD_BANDS, args.xcd_bands)
     ctx.set_shard(rank, world)
@@ -269,6 +272,7 @@ def main():
         one_frame(i)
     drain()
     torch.cuda.synchronize(dev)
+    ctx.settle()        # the work lists dealt from the warm-up frames' costs are in place before the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -298,7 +302,7 @@ def main():
             solo = demo.GpuContext(W, H, local_rank)
             solo.set_option(_lib.OPT_KERNEL, args.kernel)
             if args.layout >= 0:
-                solo.set_option(112, args.layout)
+                solo.set_option(_lib.OPT_VOLUME_LAYOUT, args.layout)
             solo.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
             solo.set_importances(importances, dims)
             solo.set_transfer_function(lut)
@@ -325,7 +329,7 @@ def main():
         solo = demo.GpuContext(W, H, local_rank)
         solo.set_option(_lib.OPT_KERNEL, args.kernel)
         if args.layout >= 0:
-            solo.set_option(112, args.layout)
+            solo.set_option(_lib.OPT_VOLUME_LAYOUT, args.layout)
         solo.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
         solo.set_importances(importances, dims)
         solo.set_transfer_function(lut)
@@ -338,6 +342,51 @@ def main():
             frame_check_result = "MISMATCH: the steady-state frame differs from a fresh context's first frame in %d bytes" % int((first != got).sum())
         else:
             frame_check_result = frame_check(args, dims, volume, importances, lut, state, got)
+
+    # ---- beside the steady state (N = 1): the first frame of a view nobody has measured (centre-first list, what a
+    # context without cost feedback runs every frame) and a moving view: a turntable of the orbit camera, every frame a new
+    # pose (src/camera.rs:47-61, src/event_loop.rs:100-119), the lists following it through the asynchronous feedback ------
+    first_frame_ms = moving_view_ms = static_views_ms = None
+    if world == 1 and args.kernel == 2 and not args.no_moving_view:
+        from volym_amd import scene
+        ctx.set_option(_lib.OPT_COST_FEEDBACK, 0)
+        ctx.update(state.camera_uniforms(), state.parameter_uniforms())
+        ctx.time_batch(5)
+        first_frame_ms = ctx.time_batch(20) / 20
+        ctx.set_option(_lib.OPT_COST_FEEDBACK, 1)
+        n_tt = args.turntable_frames
+        deg = args.turntable_degrees
+        st2 = scene.State.with_parameters(W / H, scene.StateParameters.benchmark().replace(raymarching_step_size=args.step))
+        views = []
+        for i in range(n_tt + 60):
+            st2.process_mouse(-deg / 0.2, 0.0)                    # sensitivity 0.2 degrees per pixel (src/state.rs:63)
+            st2.update()
+            views.append((st2.camera_uniforms(), st2.parameter_uniforms()))
+        # the steady state of the same views (each rendered until its own list is in place): what "static" means along the path
+        static_ms = []
+        for cu, pu in views[60::max(1, n_tt // 8)][:8]:
+            ctx.update(cu, pu)
+            ctx.time_batch(3)
+            ctx.settle()
+            static_ms.append(ctx.time_batch(10) / 10)
+        static_views_ms = float(np.mean(static_ms))
+        # the turntable itself: one update + compute pass per view, back to back, at most 3 frames ahead of the device (the
+        # back-pressure a swap chain gives the reference's loop, src/event_loop.rs:114)
+        for cu, pu in views[:60]:                                # lead-in: the feedback picks the motion up
+            ctx.update(cu, pu)
+            ctx.compute_pass()
+            ctx.throttle(3)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for cu, pu in views[60:]:
+            ctx.update(cu, pu)
+            ctx.compute_pass()
+            ctx.throttle(3)
+        torch.cuda.synchronize(dev)
+        moving_view_ms = (time.perf_counter() - t0) / n_tt * 1e3
+        ctx.update(state.camera_uniforms(), state.parameter_uniforms())   # back to the bench view for what follows
+        ctx.time_batch(3)
+        ctx.settle()
 
     # ---- roofline of the dominant kernel: HIP events on the kernel's stream, algorithmic bytes from the
     # instrumented launch (reference fetch counts) -------------------------------------------------------
@@ -398,6 +447,10 @@ def main():
             },
             "gather_check": gather_check,
             "frame_check": frame_check_result,
+            "first_frame_ms": first_frame_ms,
+            "moving_view_ms": moving_view_ms,
+            "static_views_ms": static_views_ms,
+            "moving_view": (None if moving_view_ms is None else "turntable of the orbit camera, %d views %.2f degrees apart, one update + compute pass each, back to back with at most 3 frames in flight (wall clock); static_views_ms = steady state of 8 of those views" % (args.turntable_frames, args.turntable_degrees)),
             "achieved_gbs": frame_bytes * args.steps / dt / 1e9,
             "b_alg_bytes_per_frame": frame_bytes,
             "b_alg_bytes_per_ray": frame_bytes / rays,

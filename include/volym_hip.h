@@ -19,8 +19,14 @@
  *     everything from the winit event-loop thread, src/event_loop.rs:62).
  *   - volym_set_* copy from caller memory; the caller may free immediately (as
  *     queue.write_texture does, src/gpu_resources/volume.rs:81-90).
- *   - volym_compute_pass only enqueues (src/demos/pipeline.rs:97 queue.submit);
- *     volym_sync / volym_read_* block.
+ *   - volym_update and volym_compute_pass only enqueue (src/demos/pipeline.rs:97 queue.submit): no allocation,
+ *     no stream synchronisation on their path.  The one exception is spelled out at volym_update.
+ *     Blocking calls: volym_create / volym_destroy, volym_set_* (uploads; they also wait for the frames in flight),
+ *     volym_set_option, volym_set_shard, volym_set_stream, volym_sync, volym_settle, volym_read_*, volym_packed_tiles,
+ *     volym_assemble_host, volym_stats_pass, volym_time_*; volym_blit blocks only when it has to (re)size its own target.
+ *   - the default kernel schedules its work from lists that a feedback thread inside the library re-deals from the
+ *     counted cost of earlier frames (asynchronously: a frame never waits for it, and every list renders the same
+ *     pixels); volym_settle waits until a re-deal in flight has been adopted.
  */
 #ifndef VOLYM_HIP_H
 #define VOLYM_HIP_H
@@ -32,7 +38,7 @@
 extern "C" {
 #endif
 
-#define VOLYM_ABI_VERSION 1
+#define VOLYM_ABI_VERSION 2
 
 enum {
     VOLYM_OK = 0,
@@ -55,7 +61,14 @@ enum {
                                  2 = (default) 1 + persistent workgroups, centre-first tile
                                      order, per-wave shading queue, speculative sample batches */
     VOLYM_OPT_WRITE_F32 = 2,  /* 1 = also store pre-quantisation float RGBA (parity tests) */
-    VOLYM_OPT_MACRO_CELLS = 3 /* macro cells per axis (power of two, 4..32; default 32)    */
+    VOLYM_OPT_MACRO_CELLS = 3, /* macro cells per axis (power of two, 4..32; default 32)    */
+    VOLYM_OPT_VOLUME_LAYOUT = 4, /* device layout of the NEXT volume / importance upload: -1 = by size (default: 4x4x4
+                                    bricks above 64 MiB), 0 = linear, 1 = bricks.  Invisible at this boundary. */
+    VOLYM_OPT_CULLING = 5,     /* 0 = no exact culling (projected hulls, AABB clip) in kernel 2; default 1 */
+    VOLYM_OPT_COST_FEEDBACK = 6, /* 0 = kernel 2 keeps its centre-first work list; default 1 (lists re-dealt from counted costs) */
+    VOLYM_OPT_DEPTH_PARALLEL = 7, /* tile cost from which kernel 2 marches a tile as four depth-parallel quarter items:
+                                    < 0 adaptive (-N = N/10 x a wave's fair share of the frame; -1 = default), 0 never, > 0 explicit */
+    VOLYM_OPT_XCD_BANDS = 8    /* kernels 0/1: block -> tile remap bands per XCD (0 = identity, default) */
 };
 
 /* CameraUniforms, byte-for-byte (src/gpu_resources/camera.rs:56-64; WGSL mirror
@@ -125,13 +138,23 @@ int volym_set_transfer_function(volym_ctx* ctx, const uint8_t* rgba8, uint32_t n
 
 /* --- per frame ------------------------------------------------------------------ */
 /* ComputeDemo::update_gpu_state (src/demos/pipeline.rs:208-212): GpuCamera::update +
- * GpuParameters::update.  Fails with VOLYM_E_INVALID on out-of-range parameters. */
+ * GpuParameters::update.  Fails with VOLYM_E_INVALID on out-of-range parameters.  Enqueue only; a change of the step size
+ * or of the transfer function uploads 10 KiB of tables in stream order from a ring of 8 staging buffers, and only a caller
+ * that makes 8 such changes while the device is still 8 frames behind waits for a slot. */
 int volym_update(volym_ctx* ctx, const volym_camera_uniforms* camera,
                  const volym_parameter_uniforms* parameters);
 /* ComputeDemo::compute_pass (src/demos/pipeline.rs:62-102, :214-225): enqueue one
  * ray-march of every owned tile on the context's stream; returns immediately. */
 int volym_compute_pass(volym_ctx* ctx);
 int volym_sync(volym_ctx* ctx);
+/* Back-pressure for a frame loop, the role surface.get_current_texture() plays in the reference (src/event_loop.rs:114: it
+ * blocks while the swap chain's images are all in flight).  Call once per frame after volym_compute_pass: it marks the work
+ * enqueued so far and waits until at most `max_in_flight` (1..8) such marks are outstanding.  A loop that runs hundreds of
+ * frames ahead of the device also runs hundreds of frames ahead of the cost feedback of its work lists. */
+int volym_throttle(volym_ctx* ctx, uint32_t max_in_flight);
+/* Wait until a re-deal of the work lists that is in flight (cost feedback, see the conventions above) has been adopted:
+ * the frames after it run the lists measured on the current view.  Never needed for correctness. */
+int volym_settle(volym_ctx* ctx);
 
 /* --- output --------------------------------------------------------------------- */
 /* Full-frame readback (world == 1, or after volym_assemble on the root):
@@ -139,6 +162,15 @@ int volym_sync(volym_ctx* ctx);
  * (the latter needs VOLYM_OPT_WRITE_F32 = 1). */
 int volym_read_rgba8(volym_ctx* ctx, uint8_t* out);
 int volym_read_rgba32f(volym_ctx* ctx, float* out);
+
+/* The step after the path: RenderPipeline::render_pass (src/render_pipeline.rs:88-130) with shaders/render.wgsl:39-43 --
+ * every pixel (x, y) of an out_w x out_h rgba8 target samples the frame at uv = (x + 0.5, y + 0.5) / (W, H) through a
+ * Linear / ClampToEdge sampler (src/gpu_resources/texture.rs:84-101), BlendState::REPLACE.  Note the divisor: the INPUT
+ * size, as in the shader, so the pass maps pixels 1:1 (a larger target repeats the edge texels, a smaller one crops).
+ * target_rgba8 = device memory of out_w*out_h*4 bytes, or NULL for a target the context owns (volym_read_blit reads it
+ * back).  Enqueued on the context's stream behind the frame. */
+int volym_blit(volym_ctx* ctx, void* target_rgba8, uint32_t out_w, uint32_t out_h);
+int volym_read_blit(volym_ctx* ctx, uint8_t* out);
 
 /* Sharded output.  Local buffer = volym_local_tiles() tiles of 16x16 RGBA8 pixels
  * (1024 bytes each, padded to volym_shard_bytes()); device pointer for the collective. */

@@ -121,6 +121,8 @@ def lib():
                                       C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,
                                       C.c_int, C.POINTER(C.c_double), u8p, C.POINTER(Counters)]
         L.vo_render_timed.restype = C.c_int
+        L.vo_blit.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
+        L.vo_blit.restype = C.c_int
         L.vo_render_pixel.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int,
                                       C.POINTER(CameraUniforms), C.POINTER(Parameters),
                                       C.c_int, C.c_int, C.c_int, C.c_int, f32p,
@@ -261,3 +263,13 @@ def render_timed(volume, importances, dims, lut, cam_uniforms, params, W, H, pas
     if rc != 0:
         raise ValueError("vo_render_timed failed (%d)" % rc)
     return secs, k.as_dict()
+
+
+def blit(frame_rgba8, out_w, out_h):
+    """shaders/render.wgsl:39-43: frame [H, W, 4] uint8 -> target [out_h, out_w, 4] uint8."""
+    f = np.ascontiguousarray(frame_rgba8, np.uint8)
+    H, W, _ = f.shape
+    out = np.empty((int(out_h), int(out_w), 4), np.uint8)
+    if lib().vo_blit(_u8(f), W, H, _u8(out), int(out_w), int(out_h)) != 0:
+        raise ValueError("vo_blit rejected its arguments")
+    return out

@@ -849,3 +849,42 @@ int vo_render_timed(const uint8_t* volume, const uint8_t* importances, int nx, i
     scene_init(&s, volume, importances, nx, ny, nz, filter, tf_lut, tf_n, cam, par, W, H);
     return render_parallel(&s, 0, rows ? 0 : H, rows, rows ? n_rows : 0, threads, NULL, out_u8, counters, passes, pass_seconds);
 }
+
+
+/* ------------------------------------------------------------------------- */
+/* Blit: shaders/render.wgsl:39-43 through the sampler of                      */
+/* src/gpu_resources/texture.rs:84-101 into an rgba8unorm target               */
+/* (src/render_pipeline.rs:60-64 BlendState::REPLACE).                         */
+/* ------------------------------------------------------------------------- */
+static void blit_axis(float frag, float fn, int n, int* i0, int* i1, float* w)
+{
+    float u = frag / fn;                 /* wgsl:41  uv = frag_coord.xy / textureDimensions(input_texture) */
+    float x = u * fn - 0.5f;             /* Vulkan linear filtering: unnormalised coordinate minus 0.5 */
+    float fl = floorf(x);
+    *w = x - fl;
+    int i = (int)fl;
+    *i0 = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);              /* AddressMode::ClampToEdge */
+    *i1 = i + 1 < 0 ? 0 : (i + 1 > n - 1 ? n - 1 : i + 1);
+}
+
+int vo_blit(const uint8_t* in_rgba8, int in_w, int in_h, uint8_t* out_rgba8, int out_w, int out_h)
+{
+    if (!in_rgba8 || !out_rgba8 || in_w <= 0 || in_h <= 0 || out_w <= 0 || out_h <= 0) return -1;
+    for (int y = 0; y < out_h; ++y) {
+        int y0, y1; float wy;
+        blit_axis((float)y + 0.5f, (float)in_h, in_h, &y0, &y1, &wy);      /* frag_coord = pixel centre */
+        for (int x = 0; x < out_w; ++x) {
+            int x0, x1; float wx;
+            blit_axis((float)x + 0.5f, (float)in_w, in_w, &x0, &x1, &wx);
+            for (int ch = 0; ch < 4; ++ch) {
+                float a = (float)in_rgba8[4 * ((size_t)y0 * in_w + x0) + ch] / 255.0f;
+                float b = (float)in_rgba8[4 * ((size_t)y0 * in_w + x1) + ch] / 255.0f;
+                float c = (float)in_rgba8[4 * ((size_t)y1 * in_w + x0) + ch] / 255.0f;
+                float d = (float)in_rgba8[4 * ((size_t)y1 * in_w + x1) + ch] / 255.0f;
+                float top = a * (1.0f - wx) + b * wx, bot = c * (1.0f - wx) + d * wx;
+                out_rgba8[4 * ((size_t)y * out_w + x) + ch] = to_unorm8(top * (1.0f - wy) + bot * wy);
+            }
+        }
+    }
+    return 0;
+}

@@ -132,6 +132,11 @@ int vo_render_timed(const uint8_t* volume, const uint8_t* importances, int nx, i
                     int W, int H, const int* rows, int n_rows, int threads,
                     int passes, double* pass_seconds, uint8_t* out_u8, vo_counters* counters);
 
+/* The blit that follows the path (shaders/render.wgsl:39-43, sampler src/gpu_resources/texture.rs:84-101, REPLACE blend
+ * into rgba8unorm src/render_pipeline.rs:60-64): out(x, y) = store(sample_linear_clamp(in, (x + 0.5, y + 0.5) / (in_w, in_h))).
+ * The divisor is the INPUT size, as in the shader: pixels map 1:1, a larger target repeats the edge texels. */
+int vo_blit(const uint8_t* in_rgba8, int in_w, int in_h, uint8_t* out_rgba8, int out_w, int out_h);
+
 /* one pixel, for spot checks */
 void vo_render_pixel(const uint8_t* volume, const uint8_t* importances, int nx, int ny, int nz,
                      int filter, const uint8_t* tf_lut, int tf_n,

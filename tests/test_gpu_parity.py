@@ -32,6 +32,7 @@ def _render_gpu(ctx, cam, par, variant):
     ctx.update(cu, pu)
     ctx.compute_pass()
     ctx.sync()
+    ctx.settle()        # a later frame of the same view runs the list the cost feedback dealt from this one
     return ctx.read_rgba32f(), ctx.read_rgba8(), ctx.stats_pass()
 
 
@@ -138,15 +139,16 @@ def test_teapot_config1(oracle, volym_lib):
 @pytest.mark.parametrize("filt", [0, 1], ids=["nearest", "linear"])
 def test_bricked_layout_matches_oracle(oracle, volym_lib, bonsai64, filt):
     """The 4x4x4-brick layout the library picks for volumes beyond the Infinity Cache, forced here on a small volume
-    (dev option 112): same pixels, same reference-fetch counters, every kernel variant; dimensions that are not
+    (VOLYM_OPT_VOLUME_LAYOUT): same pixels, same reference-fetch counters, every kernel variant; dimensions that are not
     multiples of 4 exercise the brick padding."""
+    from volym_amd import _lib
     raw, labels, dims, vol, imp = bonsai64
     W, H = 96, 64
     cam = oracle.benchmark_camera_uniforms(W / H)
     lut = oracle.tf_default_lut()
     combos = [f for i, f in enumerate(common.all_flag_combos()) if i % 5 == 0 or i == 31]
     with _ctx(W, H) as ctx:
-        ctx.set_option(112, 1)
+        ctx.set_option(_lib.OPT_VOLUME_LAYOUT, 1)
         _setup_ctx(ctx, raw, labels, common.BONSAI_SEGMENTS, dims, filt)
         for flags in combos:
             par = oracle.make_parameters(density_threshold=0.15, importance_check_ahead_steps=6,
@@ -162,7 +164,7 @@ def test_bricked_layout_matches_oracle(oracle, volym_lib, bonsai64, filt):
         W2, H2 = 37, 23
         cam2 = oracle.benchmark_camera_uniforms(W2 / H2, 20.0, 10.0, 0.0)
         with _ctx(W2, H2) as ctx:
-            ctx.set_option(112, 1)
+            ctx.set_option(_lib.OPT_VOLUME_LAYOUT, 1)
             ctx.set_volume(rvol, rdims, filt)
             ctx.set_importances(rimp, rdims)
             ctx.set_transfer_function(lut)
@@ -209,12 +211,12 @@ def test_random_configurations(oracle, volym_lib, seed):
         ref = oracle.render(vol, imp, dims, lut, cam, par, W, H, filter=filt)
         for layout in (0, 1):
             with _ctx(W, H) as ctx:
-                ctx.set_option(112, layout)
+                ctx.set_option(_lib.OPT_VOLUME_LAYOUT, layout)
                 ctx.set_volume(vol, dims, filt)
                 ctx.set_importances(imp, dims)
                 ctx.set_transfer_function(lut)
-                ctx.set_option(105, 1)      # every marched tile becomes depth-parallel items in the second frame
-                for frame in range(2):
+                ctx.set_option(_lib.OPT_DEPTH_PARALLEL, 1)      # every marched tile becomes depth-parallel items in the second frame
+                for frame in range(2):          # _render_gpu settles: frame 1 runs the re-dealt list (depth-parallel items)
                     _check(_render_gpu(ctx, cam, par, 2), ref,
                            "seed %d case %d dims %s %dx%d flags %s filter %d layout %d frame %d" % (seed, case, dims, W, H, common.flag_id(flags), filt, layout, frame))
                     cases += 1
@@ -302,14 +304,15 @@ def test_full_size_properties(oracle, volym_lib):
         # static view: the second frame re-sorts the work list by measured cost and marches the most expensive
         # tiles depth-parallel (four lanes per ray); forced here for EVERY marched tile as well (threshold 1)
         for thr in (-1, 1):
-            ctx.set_option(105, thr)
+            ctx.set_option(_lib.OPT_DEPTH_PARALLEL, thr)
             ctx.update(cu, pu)
             for _ in range(3):
                 ctx.compute_pass()
                 ctx.sync()
+                ctx.settle()
                 assert np.array_equal(ctx.read_rgba8(), u2), thr
                 assert np.array_equal(ctx.read_rgba32f().view(np.uint32), f2.view(np.uint32)), thr
-        ctx.set_option(105, -1)
+        ctx.set_option(_lib.OPT_DEPTH_PARALLEL, -1)
         f1, u1 = f2, u2
         # (c) oracle on every 8th row
         vol_o, imp_o = common.oracle_scene(oracle, raw, labels, common.BONSAI_SEGMENTS, dims)
@@ -414,17 +417,18 @@ def test_culling_and_feedback_leave_pixels_unchanged(oracle, volym_lib):
                 pu = _lib.ParameterUniforms.from_buffer_copy(bytes(par))
                 frames = []
                 for cull, feedback in ((0, 0), (1, 0), (1, 1)):
-                    ctx.set_option(103, cull)
-                    ctx.set_option(104, feedback)
+                    ctx.set_option(_lib.OPT_CULLING, cull)
+                    ctx.set_option(_lib.OPT_COST_FEEDBACK, feedback)
                     ctx.update(cu, pu)
-                    for _ in range(3):                       # frame 2 triggers the cost reorder when feedback is on
+                    for _ in range(3):                       # frames 2 and 3 run the re-dealt list when feedback is on
                         ctx.compute_pass()
                         ctx.sync()
+                        ctx.settle()
                         frames.append((ctx.read_rgba8(), ctx.read_rgba32f()))
                 for u, f in frames[1:]:
                     assert np.array_equal(u, frames[0][0]) and np.array_equal(f.view(np.uint32), frames[0][1].view(np.uint32)), (pose, kw)
-        ctx.set_option(103, 1)
-        ctx.set_option(104, 1)
+        ctx.set_option(_lib.OPT_CULLING, 1)
+        ctx.set_option(_lib.OPT_COST_FEEDBACK, 1)
 
 
 def test_shard_layout_matches_host_mirror(oracle, volym_lib):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(volym_lib):
     for name in sorted(declared):
         assert hasattr(volym_lib, name), name
         assert name in _lib.SIGNATURES, name
-    assert volym_lib.volym_abi_version() == 1
+    assert volym_lib.volym_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure(volym_lib):

@@ -216,3 +216,19 @@ def test_oracle_rejects_bad_arguments(oracle):
     cam = oracle.benchmark_camera_uniforms(1.0)
     with pytest.raises(ValueError):
         oracle.render(vol, imp, dims, lut, cam, oracle.make_parameters(), 0, 8)
+
+
+def test_blit_known_answers(oracle):
+    """vo_blit (shaders/render.wgsl:39-43 + src/gpu_resources/texture.rs:84-101): uv = pixel centre / INPUT size, so an
+    equal-sized target is a copy, a larger one repeats the edge texels (ClampToEdge), a smaller one crops."""
+    rng = np.random.default_rng(3)
+    f = rng.integers(0, 256, (23, 31, 4), dtype=np.uint8)
+    assert np.array_equal(oracle.blit(f, 31, 23), f)
+    big = oracle.blit(f, 40, 30)
+    assert np.array_equal(big[:23, :31], f)
+    assert np.array_equal(big[:23, 31:], np.repeat(f[:, 30:31], 9, axis=1))
+    assert np.array_equal(big[23:, :31], np.repeat(f[22:23], 7, axis=0))
+    assert np.array_equal(oracle.blit(f, 10, 5), f[:5, :10])
+    for W, H in ((1920, 1080), (1024, 768), (3840, 2160)):      # the sizes the reference and the bench use: still a copy
+        g = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+        assert np.array_equal(oracle.blit(g, W, H), g)

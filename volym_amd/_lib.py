@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("VOLYM_HIP_LIB") or os.path.join(_HERE, "libvolym_hip.
 OK, E_INVALID, E_HIP, E_NO_DEVICE, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 OPT_KERNEL, OPT_WRITE_F32, OPT_MACRO_CELLS = 1, 2, 3
-OPT_XCD_BANDS = 100
+OPT_VOLUME_LAYOUT, OPT_CULLING, OPT_COST_FEEDBACK, OPT_DEPTH_PARALLEL, OPT_XCD_BANDS = 4, 5, 6, 7, 8
 
 
 class VolymError(RuntimeError):
@@ -127,6 +127,10 @@ SIGNATURES = {
     "volym_update": (C.c_int, [_ctx, C.POINTER(CameraUniforms), C.POINTER(ParameterUniforms)]),
     "volym_compute_pass": (C.c_int, [_ctx]),
     "volym_sync": (C.c_int, [_ctx]),
+    "volym_settle": (C.c_int, [_ctx]),
+    "volym_throttle": (C.c_int, [_ctx, C.c_uint32]),
+    "volym_blit": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "volym_read_blit": (C.c_int, [_ctx, _u8p]),
     "volym_read_rgba8": (C.c_int, [_ctx, _u8p]),
     "volym_read_rgba32f": (C.c_int, [_ctx, _f32p]),
     "volym_local_tiles": (C.c_uint32, [_ctx]),

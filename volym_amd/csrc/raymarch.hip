@@ -1,20 +1,27 @@
 // libvolym_hip.so: context + C ABI (include/volym_hip.h) over the gfx950 kernels.
 // Replaces the reference's gpu_context.rs / gpu_resources/* / demos/pipeline.rs for the
 // ray-march path; citations are file:line under /root/reference/.
+//
+// Threading contract: volym_update and volym_compute_pass only enqueue -- no hipMalloc, no
+// hipFree, no stream synchronisation on their path.  Everything that allocates or waits lives in the set-up calls
+// (volym_create, volym_set_*, volym_set_option, volym_set_shard) and in the explicitly blocking ones (volym_sync,
+// volym_settle, volym_read_*, volym_stats_pass, volym_time_*).  The cost feedback of the work lists runs on a thread
+// of its own (below, "cost feedback").
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
-#include <string>
 #include <queue>
+#include <string>
 #include <vector>
 
-#include "../../include/volym_hip.h"
+#include "context.hpp"
 #include "raymarch_kernels.h"
 #include "raymarch_pq.h"
-
-#include <algorithm>
+#include "blit.h"
 
 using namespace volym;
 
@@ -27,102 +34,15 @@ static const float k_cone_cos[8] = {0x1p+0f, 0x1.6a09f6p-1f, 0x1.54442ep-20f, -0
 static const float k_cone_sin[8] = {0x0p+0f, 0x1.6a09d8p-1f, 0x1p+0f, 0x1.6a0a14p-1f,
                                     0x1.54442ep-19f, -0x1.6a099cp-1f, -0x1p+0f, -0x1.6a0a5p-1f};
 
-struct volym_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t own_stream = nullptr;
-    uint32_t W = 0, H = 0, tiles_x = 0, tiles_y = 0, n_tiles = 0;
-    uint32_t rank = 0, world = 1, n_local = 0, shard_tiles = 0;
-
-    uint8_t* d_vol = nullptr;
-    uint8_t* d_imp = nullptr;
-    uint32_t nx = 0, ny = 0, nz = 0;
-    uint32_t inx = 0, iny = 0, inz = 0;
-    int filter = VOLYM_FILTER_NEAREST;
-    uint8_t lut[256 * 4] = {};
-    uint32_t tf_n = 0;
-    bool have_vol = false, have_imp = false, have_tf = false, have_frame = false;
-
-    FrameTables* d_tables = nullptr;
-    FrameTables h_tables;
-    bool tables_dirty = true;
-    float tables_alpha_y = -1.0f;
-
-    uint8_t* d_mc = nullptr;   // per-macro-cell density maxima
-    uint8_t* d_df = nullptr;   // packed 4-bit distance field for (d_mc, thr_byte)
-    uint32_t mc_n = 32, mc_built_n = 0;
-    uint32_t df_thr_byte = 0xffffffffu;
-    uint32_t thr_byte_cull = 256;   // threshold byte the macro-cell occupancy is built for (conservative in continuous modes)
-    bool mc_dirty = true;
-
-    uint32_t* d_shard_own = nullptr;
-    uint32_t* d_frame_own = nullptr;
-    uint32_t* d_shard = nullptr;
-    uint32_t* d_frame = nullptr;
-    float4* d_f32 = nullptr;
-    uint8_t* d_gather_tmp = nullptr;
-    uint32_t* d_pack_counters = nullptr;   // volym_pack_shard: slot counters of even / odd launches, overflow flag
-    uint32_t pack_parity = 0;
-    size_t gather_tmp_bytes = 0;
-    Counters* d_counters = nullptr;
-    uint4* d_trace = nullptr;   // development aid, see volym_dev_wave_trace
-    uint32_t* d_order = nullptr;   // variant 2: this rank's 8x8 wave tiles, centre-first (or by measured cost)
-    std::vector<uint32_t> h_order;   // the geometric (centre-first) list, kept for re-sorting
-    uint16_t* d_cost = nullptr;    // per item: cost the last plain launch measured (loop iterations, flushes)
-    uint32_t frames_since_change = 0;
-    bool order_by_cost = false;    // d_order currently reflects measured cost
-    bool feedback = true;
-    bool super_fill = true;
-    uint32_t prio_tenths[3] = {3, 6, 10};   // cost / fair share (tenths) from which an item runs at issue priority 1, 2, 3 (first 0: off)
-    bool dev_only_quarters = false;
-    bool bricked = false;          // layout of d_vol / d_imp (raymarch_device.h "Volume layout")
-    uint64_t brick_from_bytes = 64ull << 20;    // volumes above this many bytes are bricked (512^3 at 1080p: 54.3 -> 39.7 us; 256^3: 36.6 -> 38.1)
-    int layout_choice = -1;        // -1: by size, 0: linear, 1: bricked (dev option 112, before the uploads)
-    size_t order_capacity = 0;     // entries d_order can hold
-    uint32_t order_grid = 0;       // workgroups the cost-ordered list was dealt to (0: the geometric list, any grid)
-    uint32_t dp_share_pct = 60;    // a quarter item's wave time as a percentage of the time its tile took as one item
-    uint32_t fill_cost = 2;        // cost units charged for a constant 8x8 tile when balancing
-    int dp_min_cost = -1;          // measured tile cost from which a tile is marched depth-parallel (0 = never, < 0 = adaptive)
-    uint32_t n_items = 0;
-    bool order_dirty = true;
-    int n_cus = 256;
-    uint32_t wgs_per_cu = 1;
-    int kspec = 4;
-    bool culling = true;
-    int* d_aabb = nullptr;          // occupied macro cells: {xmin, ymin, zmin, xmax, ymax, zmax}
-    int h_aabb[6] = {0, 0, 0, -1, -1, -1};
-    bool hull_dirty = true;
-    volym_camera_uniforms cam_copy;
-    volym_parameter_uniforms par_copy;
-
-    FrameParams fp;
-    int kernel_variant = 2;
-    bool write_f32 = false;
-    uint32_t xcd_bands = 0;
-    std::string err;
-};
-
 static thread_local std::string g_create_error;
 
-static int fail(volym_ctx* c, int code, const std::string& msg)
+int volym::ctx_fail(volym_ctx* c, int code, const std::string& msg)
 {
     if (c) c->err = msg; else g_create_error = msg;
     return code;
 }
-
-#define HIPCHK(ctx, expr)                                                                      \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail(ctx, VOLYM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-// anything that changes what a tile costs: measured costs no longer apply
-static void invalidate_costs(volym_ctx* c)
-{
-    c->frames_since_change = 0;
-    if (c->order_by_cost) c->order_dirty = true;
-}
+static int fail(volym_ctx* c, int code, const std::string& msg) { return ctx_fail(c, code, msg); }
+#define HIPCHK(ctx, expr) VOLYM_HIPCHK(ctx, expr)
 
 static void recompute_shard(volym_ctx* c)
 {
@@ -130,248 +50,7 @@ static void recompute_shard(volym_ctx* c)
     c->shard_tiles = (c->n_tiles + c->world - 1) / c->world;   // equal-sized shards, padded
 }
 
-extern "C" {
-
-int volym_abi_version(void) { return VOLYM_ABI_VERSION; }
-
-const char* volym_last_error(const volym_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
-
-int volym_create(volym_ctx** out, uint32_t width, uint32_t height, int device_id)
-{
-    if (!out) return fail(nullptr, VOLYM_E_INVALID, "volym_create: out is NULL");
-    *out = nullptr;
-    if (width == 0 || height == 0 || width > 32768 || height > 32768)
-        return fail(nullptr, VOLYM_E_INVALID, "volym_create: viewport must be 1..32768 in each dimension");
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
-        return fail(nullptr, VOLYM_E_NO_DEVICE, "volym_create: no HIP device visible");
-    int dev = device_id;
-    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
-    if (dev >= n_dev) return fail(nullptr, VOLYM_E_NO_DEVICE, "volym_create: device_id out of range");
-    hipDeviceProp_t prop;
-    HIPCHK(nullptr, hipGetDeviceProperties(&prop, dev));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(nullptr, VOLYM_E_NO_DEVICE,
-                    std::string("volym_create: this library carries gfx950 code only, device is ") + prop.gcnArchName);
-    HIPCHK(nullptr, hipSetDevice(dev));
-
-    volym_ctx* c = new (std::nothrow) volym_ctx();
-    if (!c) return fail(nullptr, VOLYM_E_NOMEM, "volym_create: out of host memory");
-    c->device = dev;
-    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->W = width; c->H = height;
-    c->tiles_x = (width + 15u) / 16u;     // src/demos/pipeline.rs:83-87
-    c->tiles_y = (height + 15u) / 16u;
-    c->n_tiles = c->tiles_x * c->tiles_y;
-    recompute_shard(c);
-    std::memset(&c->fp, 0, sizeof c->fp);
-    std::memset(&c->h_tables, 0, sizeof c->h_tables);
-
-    auto bail = [&](hipError_t e, const char* what) {
-        std::string m = std::string(what) + ": " + hipGetErrorString(e);
-        volym_destroy(c);
-        return fail(nullptr, e == hipErrorOutOfMemory ? VOLYM_E_NOMEM : VOLYM_E_HIP, m);
-    };
-    hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-    c->stream = c->own_stream;
-    const size_t frame_bytes = static_cast<size_t>(width) * height * 4;
-    if ((e = hipMalloc(&c->d_frame_own, frame_bytes)) != hipSuccess) return bail(e, "hipMalloc(frame)");
-    if ((e = hipMalloc(&c->d_shard_own, static_cast<size_t>(c->n_tiles) * 1024)) != hipSuccess) return bail(e, "hipMalloc(shard)");
-    if ((e = hipMalloc(&c->d_tables, sizeof(FrameTables))) != hipSuccess) return bail(e, "hipMalloc(tables)");
-    if ((e = hipMalloc(&c->d_counters, sizeof(Counters))) != hipSuccess) return bail(e, "hipMalloc(counters)");
-    if ((e = hipMemset(c->d_frame_own, 0, frame_bytes)) != hipSuccess) return bail(e, "hipMemset(frame)");
-    if ((e = hipMalloc(&c->d_aabb, 6 * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(aabb)");
-
-    c->d_frame = c->d_frame_own;
-    c->d_shard = c->d_shard_own;
-    *out = c;
-    return VOLYM_OK;
-}
-
-void volym_destroy(volym_ctx* c)
-{
-    if (!c) return;
-    (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->d_vol); (void)hipFree(c->d_imp); (void)hipFree(c->d_tables); (void)hipFree(c->d_mc); (void)hipFree(c->d_df);
-    (void)hipFree(c->d_shard_own); (void)hipFree(c->d_frame_own); (void)hipFree(c->d_f32);
-    (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_pack_counters); (void)hipFree(c->d_counters); (void)hipFree(c->d_order); (void)hipFree(c->d_cost); (void)hipFree(c->d_aabb);
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-    delete c;
-}
-
-int volym_set_stream(volym_ctx* c, void* hip_stream)
-{
-    if (!c) return VOLYM_E_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
-    return VOLYM_OK;
-}
-
-int volym_set_option(volym_ctx* c, int key, int value)
-{
-    if (!c) return VOLYM_E_INVALID;
-    invalidate_costs(c);
-    switch (key) {
-    case VOLYM_OPT_KERNEL:
-        if (value < 0 || value > 2) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_KERNEL: 0 (direct), 1 (macro-cell) or 2 (persistent + shading queue)");
-        c->kernel_variant = value;
-        return VOLYM_OK;
-    case VOLYM_OPT_WRITE_F32:
-        c->write_f32 = value != 0;
-        return VOLYM_OK;
-    case VOLYM_OPT_MACRO_CELLS:
-        if (value < 4 || value > 32 || (value & (value - 1)) != 0)
-            return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_MACRO_CELLS: power of two in 4..32");
-        c->mc_n = static_cast<uint32_t>(value);
-        c->mc_dirty = true;
-        return VOLYM_OK;
-    case 101:   // undocumented tuning knob: persistent workgroups per CU (variant 2)
-        if (value < 1 || value > 8) return fail(c, VOLYM_E_INVALID, "workgroups per CU: 1..8");
-        c->wgs_per_cu = static_cast<uint32_t>(value);
-        return VOLYM_OK;
-    case 102:   // undocumented tuning knob: speculation depth of variant 2 (1, 2 or 4)
-        if (value != 4) return fail(c, VOLYM_E_INVALID, "speculation depth: 4 (the shallower variants were dropped)");
-        c->kspec = value;
-        return VOLYM_OK;
-    case 105:   // undocumented: measured cost from which tiles are marched depth-parallel (0 = never)
-        if (value < -100 || value > 65535) return fail(c, VOLYM_E_INVALID, "dp cost threshold: < 0 adaptive (-N = N/10 x fair share), 0 off, else explicit");
-        c->dp_min_cost = value;
-        c->order_dirty = true;
-        return VOLYM_OK;
-    case 108:   // undocumented: issue-priority thresholds t1 + 100*t2 + 10000*t3 in tenths of the fair share (0 = no priorities)
-        if (value < 0) return fail(c, VOLYM_E_INVALID, "priority thresholds: t1 + 100*t2 + 10000*t3, tenths of the fair share");
-        c->prio_tenths[0] = static_cast<uint32_t>(value % 100);
-        c->prio_tenths[1] = static_cast<uint32_t>((value / 100) % 100);
-        c->prio_tenths[2] = static_cast<uint32_t>(value / 10000);
-        c->order_dirty = true;
-        return VOLYM_OK;
-    case 110:   // undocumented experiment: FrameParams::dev
-        c->fp.dev = static_cast<uint32_t>(value);
-        return VOLYM_OK;
-    case 112:   // undocumented: volume layout, -1 by size / 0 linear / 1 bricked; set before volym_set_volume / volym_set_importances
-        if (value < -1 || value > 1) return fail(c, VOLYM_E_INVALID, "layout: -1, 0 or 1");
-        c->layout_choice = value;
-        return VOLYM_OK;
-    case 111:   // undocumented: balancing estimates, dp_share_pct + 1000 * fill_cost
-        c->dp_share_pct = static_cast<uint32_t>(value % 1000);
-        c->fill_cost = static_cast<uint32_t>(value / 1000);
-        c->order_dirty = true;
-        return VOLYM_OK;
-    case 109:   // undocumented experiment: keep only the depth-parallel items in the work list (the frame is then incomplete)
-        c->dev_only_quarters = value != 0;
-        c->order_dirty = true;
-        return VOLYM_OK;
-    case 107:   // undocumented: 0 disables the 16x16 super fill items (A/B tests)
-        c->super_fill = value != 0;
-        c->order_dirty = true;
-        return VOLYM_OK;
-    case 104:   // undocumented: 0 disables the cost-feedback reordering of variant 2 (A/B tests)
-        c->feedback = value != 0;
-        c->order_dirty = true;
-        return VOLYM_OK;
-    case 103:   // undocumented: 0 disables the exact culling of variant 2 (A/B tests)
-        c->culling = value != 0;
-        c->hull_dirty = true;
-        return VOLYM_OK;
-    case 100:   // undocumented tuning knob: block->tile remap bands per XCD (0 = identity)
-        if (value < 0 || value > 64) return fail(c, VOLYM_E_INVALID, "xcd bands: 0..64");
-        c->xcd_bands = static_cast<uint32_t>(value);
-        return VOLYM_OK;
-    default:
-        return fail(c, VOLYM_E_INVALID, "volym_set_option: unknown key");
-    }
-}
-
-int volym_set_shard(volym_ctx* c, uint32_t rank, uint32_t world)
-{
-    if (!c) return VOLYM_E_INVALID;
-    if (world == 0 || rank >= world || world > 4096) return fail(c, VOLYM_E_INVALID, "volym_set_shard: need rank < world <= 4096");
-    c->rank = rank; c->world = world;
-    recompute_shard(c);
-    c->order_dirty = true;
-    return VOLYM_OK;
-}
-
-static bool want_bricked(const volym_ctx* c, uint32_t nx, uint32_t ny, uint32_t nz);
-
-static int upload_volume(volym_ctx* c, uint8_t** dst, const uint8_t* src, uint32_t nx, uint32_t ny, uint32_t nz)
-{
-    const bool bricked = want_bricked(c, nx, ny, nz);
-    if (!src || nx == 0 || ny == 0 || nz == 0) return fail(c, VOLYM_E_INVALID, "volume: NULL data or zero dimension");
-    const uint64_t n = static_cast<uint64_t>(nx) * ny * nz;
-    const uint64_t nb = bricked ? static_cast<uint64_t>(brick_count(nx)) * brick_count(ny) * brick_count(nz) * 64u : n;
-    if (nx > 4096 || ny > 4096 || nz > 4096 || nb > 0xffffffffull)
-        return fail(c, VOLYM_E_INVALID, "volume: each dimension <= 4096 and the brick-padded size < 2^32");
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (*dst) { HIPCHK(c, hipFree(*dst)); *dst = nullptr; }
-    uint8_t* staging = nullptr;
-    hipError_t e = hipMalloc(dst, nb + 16);      // the trilinear fetch reads voxel pairs: one byte past the last voxel is touched
-    if (e == hipSuccess) e = hipMemset(*dst + nb, 0, 16);
-    if (e == hipSuccess && bricked) e = hipMalloc(&staging, n);
-    if (e != hipSuccess) { (void)hipFree(staging); return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(volume): ") + hipGetErrorString(e)); }
-    e = hipMemcpy(bricked ? staging : *dst, src, n, hipMemcpyHostToDevice);
-    if (e == hipSuccess && bricked) {
-        hipLaunchKernelGGL(volym_rebrick_kernel, dim3(static_cast<uint32_t>((nb + 255u) / 256u)), dim3(256), 0, c->stream, staging, *dst, nx, ny, nz);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    }
-    (void)hipFree(staging);
-    if (e != hipSuccess) return fail(c, VOLYM_E_HIP, std::string("volume upload: ") + hipGetErrorString(e));
-    return VOLYM_OK;
-}
-
-// Bricks pay once the volume outgrows the L2s (measured: from 512^3 on; see raymarch_device.h); volume and importances of
-// the same dimensions get the same answer.
-static bool want_bricked(const volym_ctx* c, uint32_t nx, uint32_t ny, uint32_t nz)
-{
-    if (c->layout_choice >= 0) return c->layout_choice == 1;
-    return static_cast<uint64_t>(nx) * ny * nz > c->brick_from_bytes;
-}
-
-int volym_set_volume(volym_ctx* c, const uint8_t* voxels, uint32_t nx, uint32_t ny, uint32_t nz, int filter)
-{
-    if (!c) return VOLYM_E_INVALID;
-    if (filter != VOLYM_FILTER_NEAREST && filter != VOLYM_FILTER_LINEAR)
-        return fail(c, VOLYM_E_INVALID, "volym_set_volume: filter must be VOLYM_FILTER_NEAREST or VOLYM_FILTER_LINEAR");
-    int rc = upload_volume(c, &c->d_vol, voxels, nx, ny, nz);
-    if (rc != VOLYM_OK) { c->have_vol = false; return rc; }
-    c->nx = nx; c->ny = ny; c->nz = nz; c->filter = filter;
-    c->bricked = want_bricked(c, nx, ny, nz);
-    c->have_vol = true;
-    c->mc_dirty = true;
-    invalidate_costs(c);
-    return VOLYM_OK;
-}
-
-int volym_set_importances(volym_ctx* c, const uint8_t* importances, uint32_t nx, uint32_t ny, uint32_t nz)
-{
-    if (!c) return VOLYM_E_INVALID;
-    int rc = upload_volume(c, &c->d_imp, importances, nx, ny, nz);
-    if (rc != VOLYM_OK) { c->have_imp = false; return rc; }
-    c->inx = nx; c->iny = ny; c->inz = nz;
-    c->have_imp = true;
-    invalidate_costs(c);
-    return VOLYM_OK;
-}
-
-int volym_set_transfer_function(volym_ctx* c, const uint8_t* rgba8, uint32_t n)
-{
-    if (!c) return VOLYM_E_INVALID;
-    if (!rgba8 || n < 1 || n > 256) return fail(c, VOLYM_E_INVALID, "volym_set_transfer_function: 1..256 RGBA8 texels");
-    std::memset(c->lut, 0, sizeof c->lut);
-    std::memcpy(c->lut, rgba8, static_cast<size_t>(n) * 4);
-    c->tf_n = n;
-    c->have_tf = true;
-    c->tables_dirty = true;
-    invalidate_costs(c);
-    return VOLYM_OK;
-}
-
-}  // extern "C"
+static uint32_t max_grid(const volym_ctx* c) { return static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu; }
 
 // ---- host-side table construction (EXACT arithmetic, same recipe as the device) --------------
 static void host_texel_linear(float u, int n, int& i0, int& i1, float& w)
@@ -386,9 +65,8 @@ static void host_texel_linear(float u, int n, int& i0, int& i1, float& w)
     i1 = i + 1 < 0 ? 0 : (i + 1 > n - 1 ? n - 1 : i + 1);
 }
 
-static void build_tables(volym_ctx* c, float alpha_y)
+static void build_tables(volym_ctx* c, FrameTables& t, float alpha_y)
 {
-    FrameTables& t = c->h_tables;
     const int n = static_cast<int>(c->tf_n);
     for (int b = 0; b < 256; ++b) {
         t.rho[b] = static_cast<float>(b) / 255.0f;
@@ -407,157 +85,7 @@ static void build_tables(volym_ctx* c, float alpha_y)
                                   1.0f - wgsl_pow(1.0f - A, alpha_y));   // wgsl:314
         t.ic_alpha[b] = 1.0f - wgsl_pow(1.0f - t.rho[b], alpha_y);       // wgsl:83-84, :314
     }
-}
-
-// Variant 2 work list: the 8x8-pixel wave tiles of this rank's 16x16 tiles (item = local_tile*4 + sub),
-// sorted by Chebyshev distance of the tile centre from the screen centre.  The orbit camera always
-// targets the volume centre (src/camera.rs:23), so the long rays are the central ones: they start first.
-static int build_order(volym_ctx* c)
-{
-    std::vector<std::pair<uint32_t, uint32_t>> keyed;
-    keyed.reserve(static_cast<size_t>(c->n_local) * 4);
-    for (uint32_t lt = 0; lt < c->n_local; ++lt) {
-        const uint32_t tile = lt * c->world + c->rank;
-        const uint32_t tx = tile % c->tiles_x, ty = tile / c->tiles_x;
-        for (uint32_t sub = 0; sub < 4; ++sub) {
-            const int x0 = static_cast<int>(tx * 16u + (sub & 1u) * 8u), y0 = static_cast<int>(ty * 16u + (sub >> 1) * 8u);
-            if (x0 >= static_cast<int>(c->W) || y0 >= static_cast<int>(c->H)) {
-                if (c->world == 1) continue;          // wholly outside the frame: nothing to store in raster mode
-            }
-            const int dx = std::abs(2 * x0 + 8 - static_cast<int>(c->W)), dy = std::abs(2 * y0 + 8 - static_cast<int>(c->H));
-            // rings of 16 pixels; inside a ring a hash decides, so that a workgroup (which takes every G-th item)
-            // does not sit at the same angular position on every ring
-            const uint32_t item = lt * 4u + sub;
-            uint32_t h = item * 0x9E3779B1u;
-            h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
-            keyed.emplace_back((static_cast<uint32_t>(std::max(dx, dy)) / 32u) << 20 | (h & 0xfffffu), item);
-        }
-    }
-    std::sort(keyed.begin(), keyed.end());
-    std::vector<uint32_t> order(keyed.size());
-    for (size_t i = 0; i < keyed.size(); ++i) order[i] = keyed[i].second;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->d_order) { HIPCHK(c, hipFree(c->d_order)); c->d_order = nullptr; }
-    if (c->d_cost) { HIPCHK(c, hipFree(c->d_cost)); c->d_cost = nullptr; }
-    c->n_items = static_cast<uint32_t>(order.size());
-    if (c->n_items) {
-        c->order_capacity = order.size() * 4;
-        c->order_grid = 0;
-        hipError_t e = hipMalloc(&c->d_order, c->order_capacity * sizeof(uint32_t));   // room for quarter-tile items
-        if (e == hipSuccess) e = hipMalloc(&c->d_cost, static_cast<size_t>(c->n_local) * 4 * sizeof(uint16_t));
-        if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(order): ") + hipGetErrorString(e));
-        HIPCHK(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemset(c->d_cost, 0, static_cast<size_t>(c->n_local) * 4 * sizeof(uint16_t)));
-    }
-    c->h_order = std::move(order);
-    c->order_dirty = false;
-    c->order_by_cost = false;
-    c->frames_since_change = 0;
-    return VOLYM_OK;
-}
-
-// Scheduling feedback (variant 2).  The frame time is set by the few hundred tiles whose rays take ~10x the
-// average number of dependent samples; they should be the first tickets of every workgroup, and only the
-// previous frame knows which they are.  When a second frame is requested with nothing changed (the
-// reference's benchmark and an idle window render a static view; an orbiting camera never gets here) the
-// work list is re-sorted once by the cost the last launch measured, longest first; ties keep the
-// centre-first order.  Pixels do not depend on the order.
-static int reorder_by_cost(volym_ctx* c)
-{
-    if (!c->n_items || !c->d_cost) return VOLYM_OK;
-    std::vector<uint16_t> cost(static_cast<size_t>(c->n_local) * 4);
-    HIPCHK(c, hipMemcpyAsync(cost.data(), c->d_cost, cost.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    // Tiles above dp_min_cost are split into four 4x4 quarter tiles marched depth-parallel (raymarch_pq.h):
-    // their cost is a long chain of dependent samples, which four lanes per ray walk ~4x faster, on four waves.
-    // Which tiles?  Those that would keep one wave busy for more than about twice a wave's fair share of the
-    // frame (sum of costs / resident waves): below that they hide in the bulk and splitting only adds work.
-    uint64_t total_cost = 0;
-    for (uint32_t item : c->h_order) total_cost += cost[item];
-    const uint32_t resident_waves = static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu * PQ_WAVES;
-    // dp_min_cost < 0 encodes the factor in tenths (-20 = 2.0 x fair share, the default -1 means 2.0)
-    // measured optimum: 1.5x for the table mode, 1.2x for the continuous-rho modes (their classic loop speculates only two
-    // samples deep, a depth-parallel item four)
-    const bool continuous = (c->fp.flags & (F_LINEAR | F_GAUSSIAN)) != 0u;
-    const uint64_t tenths = c->dp_min_cost < -1 ? static_cast<uint64_t>(-c->dp_min_cost) : (continuous ? 12u : 15u);
-    const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(64, tenths * total_cost / (10u * std::max(1u, resident_waves)) + 16));
-    const uint32_t dp_thr = c->dp_min_cost < 0 ? adaptive : static_cast<uint32_t>(c->dp_min_cost);
-    const bool dp_ok = c->dp_min_cost != 0;
-    std::vector<std::pair<uint32_t, uint32_t>> keyed;      // (cost share, item)
-    keyed.reserve(c->h_order.size() * 2);
-    // 16x16 tiles whose four sub-tiles were all constant become one "super" fill item (bit 30)
-    std::vector<uint8_t> all_fill(c->n_local, 1), seen(c->n_local, 0);
-    for (uint32_t item : c->h_order) if (cost[item] != 0) all_fill[item >> 2] = 0;
-    {
-        std::vector<uint8_t> cnt(c->n_local, 0);
-        for (uint32_t item : c->h_order) cnt[item >> 2]++;
-        for (uint32_t lt = 0; lt < c->n_local; ++lt) if (cnt[lt] != 4) all_fill[lt] = 0;   // sub-tiles outside the frame are not listed
-    }
-    for (uint32_t item : c->h_order) {
-        const uint32_t k = cost[item];
-        if (c->super_fill && all_fill[item >> 2]) {
-            if (!seen[item >> 2]) { seen[item >> 2] = 1; keyed.emplace_back(0u, 0x40000000u | (item >> 2)); }
-            continue;
-        }
-        if (dp_ok && k >= dp_thr)
-            for (uint32_t qd = 0; qd < 4; ++qd) keyed.emplace_back((k * c->dp_share_pct + 99u) / 100u, 0x80000000u | (item << 2) | qd);
-        else
-            keyed.emplace_back(k, item);
-    }
-    std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first > b.first; });
-    if (c->dev_only_quarters) {     // experiment: how long do the depth-parallel items take with the machine to themselves?
-        std::vector<std::pair<uint32_t, uint32_t>> q;
-        for (const auto& kv : keyed) if (kv.second >> 31) q.push_back(kv);
-        keyed.swap(q);
-    }
-    // issue priority (bits 28-29) from the item's cost relative to a wave's fair share of the frame
-    const uint64_t fair = std::max<uint64_t>(1, total_cost / std::max(1u, resident_waves));
-    const bool prio_ok = c->prio_tenths[0] > 0 && static_cast<uint64_t>(c->n_local) * 16u < (1u << 28);
-    // Workgroup b reads items b, b + G, ... of the list.  The lists are filled longest-processing-time first: every item,
-    // in order of decreasing cost, goes to the workgroup with the least work so far, so the sums differ by less than one
-    // item; shorter lists are padded with PQ_NO_ITEM.
-    const uint32_t n_keyed = static_cast<uint32_t>(keyed.size());
-    const uint32_t G = std::max(1u, std::min((n_keyed + PQ_WAVES - 1) / PQ_WAVES, static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu));
-    std::vector<std::vector<uint32_t>> lists(G);
-    {
-        typedef std::pair<uint64_t, uint32_t> Load;      // (work so far, workgroup)
-        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
-        for (uint32_t b = 0; b < G; ++b) heap.emplace(0u, b);
-        for (const auto& kv : keyed) {
-            uint32_t prio = 0;
-            if (prio_ok && kv.first) {
-                const uint64_t k10 = static_cast<uint64_t>(kv.first) * 10u;
-                prio = k10 >= c->prio_tenths[2] * fair ? 3u : k10 >= c->prio_tenths[1] * fair ? 2u : k10 >= c->prio_tenths[0] * fair ? 1u : 0u;
-            }
-            Load l = heap.top();
-            heap.pop();
-            lists[l.second].push_back(kv.second | (prio << 28));
-            // constant tiles were measured as 0: a store of 64 or 256 pixels is not free
-            const uint32_t floor_share = ((kv.second >> 30) == 1u) ? c->fill_cost * 3u : c->fill_cost;
-            l.first += std::max(kv.first, floor_share);
-            heap.push(l);
-        }
-    }
-    size_t maxlen = 0;
-    for (const auto& l : lists) maxlen = std::max(maxlen, l.size());
-    std::vector<uint32_t> order(static_cast<size_t>(G) * maxlen, PQ_NO_ITEM);
-    for (uint32_t b = 0; b < G; ++b)
-        for (size_t i = 0; i < lists[b].size(); ++i) order[b + static_cast<size_t>(G) * i] = lists[b][i];
-    if (order.size() > c->order_capacity) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipFree(c->d_order));
-        c->d_order = nullptr;
-        HIPCHK(c, hipMalloc(&c->d_order, order.size() * sizeof(uint32_t)));
-        c->order_capacity = order.size();
-    }
-    c->n_items = static_cast<uint32_t>(order.size());
-    c->order_grid = G;
-    HIPCHK(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    c->order_by_cost = true;
-    return VOLYM_OK;
-}
-
-// ---- exact culling inputs (raymarch_pq.h): hulls of the projected unit cube and of the projected AABB of the
+}// ---- exact culling inputs (raymarch_pq.h): hulls of the projected unit cube and of the projected AABB of the
 // occupied macro cells, in pixel coordinates, plus the AABB itself.  Double precision on the host; the kernel
 // applies a 1.5 pixel margin, far above the f32 noise of the per-pixel ray set-up it stands in for. ----
 namespace {
@@ -618,15 +146,17 @@ static void compute_culling(volym_ctx* c)
     std::memset(fp.hull, 0, sizeof fp.hull);
     c->hull_dirty = false;
     if (!c->culling) return;
-    // AABB of the occupied cells, grown by what a sample may reach beyond its own position
-    const bool none = c->h_aabb[3] < c->h_aabb[0];
+    // AABB of the occupied cells (per threshold byte, computed when the volume was set), grown by what a sample may
+    // reach beyond its own position
+    const int* h_aabb = c->aabb_tab[std::min(c->thr_byte_cull, 256u)];
+    const bool none = h_aabb[3] < h_aabb[0];
     if (none) fp.cull |= CULL_NOTHING_DENSE;
     double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
     const double margin = 1.0e-4 + ((fp.flags & F_GAUSSIAN) ? 0.0101 : 0.0);   // smoothing taps sit up to 2*0.005 along the ray (wgsl:53-60)
     if (!none) {
         for (int i = 0; i < 3; ++i) {
-            lo[i] = static_cast<double>(c->h_aabb[i]) / c->mc_n - margin;
-            hi[i] = static_cast<double>(c->h_aabb[3 + i] + 1) / c->mc_n + margin;
+            lo[i] = static_cast<double>(h_aabb[i]) / c->mc_n - margin;
+            hi[i] = static_cast<double>(h_aabb[3 + i] + 1) / c->mc_n + margin;
             fp.aabb_lo[i] = static_cast<float>(lo[i]);
             fp.aabb_hi[i] = static_cast<float>(hi[i]);
         }
@@ -660,36 +190,624 @@ static void compute_culling(volym_ctx* c)
     if (project_box(c0, c1, fp.hull[0])) fp.cull |= CULL_CUBE_HULL;
     if (!none && project_box(lo, hi, fp.hull[1])) fp.cull |= CULL_OBJ_HULL;
 }
+// ================================================================================================================
+// Work lists and their cost feedback (variant 2).
+//
+// The kernel's persistent workgroups read a list of items; the frame time is set by how well that list balances the few
+// hundred tiles whose rays take ~10x the average number of dependent samples.  Only a rendered frame knows which they
+// are, so a launch can be asked to report a counted cost per list entry ("capture"): the costs are copied to pinned host
+// memory on a second stream, and a feedback THREAD -- never the caller -- turns them into the next list: most expensive
+// entries first and dealt longest-processing-time first to the workgroups, the most expensive tiles split into four
+// depth-parallel quarter items, constant 16x16 tiles merged into super-fill items.  The caller's volym_compute_pass only
+// looks at an atomic flag: when a new list is ready it switches to it between two launches.  Lists are scheduling only:
+// every list renders the same pixels, so a list measured on a neighbouring view is a good list for this one, and a
+// moving camera simply keeps the feedback running (one capture in flight at a time).
+// ================================================================================================================
 
+// geometric list: the 8x8-pixel wave tiles of this rank's 16x16 tiles (item = local_tile*4 + sub), by Chebyshev
+// distance of the tile centre from the screen centre.  The orbit camera always targets the volume centre
+// (src/camera.rs:23), so the long rays are the central ones: they start first.
+static void build_geometric(volym_ctx* c)
+{
+    std::vector<std::pair<uint32_t, uint32_t>> keyed;
+    keyed.reserve(static_cast<size_t>(c->n_local) * 4);
+    for (uint32_t lt = 0; lt < c->n_local; ++lt) {
+        const uint32_t tile = lt * c->world + c->rank;
+        const uint32_t tx = tile % c->tiles_x, ty = tile / c->tiles_x;
+        for (uint32_t sub = 0; sub < 4; ++sub) {
+            const int x0 = static_cast<int>(tx * 16u + (sub & 1u) * 8u), y0 = static_cast<int>(ty * 16u + (sub >> 1) * 8u);
+            if (x0 >= static_cast<int>(c->W) || y0 >= static_cast<int>(c->H)) {
+                if (c->world == 1) continue;          // wholly outside the frame: nothing to store in raster mode
+            }
+            const int dx = std::abs(2 * x0 + 8 - static_cast<int>(c->W)), dy = std::abs(2 * y0 + 8 - static_cast<int>(c->H));
+            // rings of 16 pixels; inside a ring a hash decides, so that a workgroup (which takes every G-th item)
+            // does not sit at the same angular position on every ring
+            const uint32_t item = lt * 4u + sub;
+            uint32_t h = item * 0x9E3779B1u;
+            h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+            keyed.emplace_back((static_cast<uint32_t>(std::max(dx, dy)) / 32u) << 20 | (h & 0xfffffu), item);
+        }
+    }
+    std::sort(keyed.begin(), keyed.end());
+    c->geometric.resize(keyed.size());
+    for (size_t i = 0; i < keyed.size(); ++i) c->geometric[i] = keyed[i].second;
+}
+
+// Deal `item_cost` into a list (feedback thread; also the caller's thread inside blocking set-up calls).
+static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std::vector<uint16_t>& measured_cost, std::vector<uint8_t>& item_is_dp,
+                      const std::vector<uint32_t>& geometric, uint32_t n_local, WorkList& out)
+{
+    const uint32_t waves = job.waves;
+    // The costs were measured on an earlier frame; when the camera moves, what was expensive there is expensive a tile or two
+    // further on here.  A maximum filter over the neighbouring 8x8 items (radius job.dilate) makes the list hold for a
+    // while: the price is a few tiles split or started early that did not need it.
+    std::vector<uint16_t> item_cost(measured_cost);
+    // has the camera moved since the captured frame?  Then the list will be read on yet another view
+    const int dilate = job.dilate >= 0 ? job.dilate : (c->view_serial.load(std::memory_order_relaxed) != job.view_serial ? 1 : 0);
+    if (dilate > 0) {
+        const uint32_t gw = c->tiles_x * 2u, gh = c->tiles_y * 2u;
+        std::vector<uint16_t> grid(static_cast<size_t>(gw) * gh, 0), tmp(static_cast<size_t>(gw) * gh, 0);
+        auto cell_of = [&](uint32_t item) {
+            const uint32_t tile = (item >> 2) * c->world + c->rank, sub = item & 3u;
+            return static_cast<size_t>((tile / c->tiles_x) * 2u + (sub >> 1)) * gw + (tile % c->tiles_x) * 2u + (sub & 1u);
+        };
+        for (uint32_t item : geometric) grid[cell_of(item)] = measured_cost[item];
+        const int r = dilate;
+        for (uint32_t y = 0; y < gh; ++y)
+            for (uint32_t x = 0; x < gw; ++x) {
+                uint16_t m = 0;
+                for (int d = -r; d <= r; ++d) { const int xx = static_cast<int>(x) + d; if (xx >= 0 && xx < static_cast<int>(gw)) m = std::max(m, grid[static_cast<size_t>(y) * gw + xx]); }
+                tmp[static_cast<size_t>(y) * gw + x] = m;
+            }
+        for (uint32_t y = 0; y < gh; ++y)
+            for (uint32_t x = 0; x < gw; ++x) {
+                uint16_t m = 0;
+                for (int d = -r; d <= r; ++d) { const int yy = static_cast<int>(y) + d; if (yy >= 0 && yy < static_cast<int>(gh)) m = std::max(m, tmp[static_cast<size_t>(yy) * gw + x]); }
+                grid[static_cast<size_t>(y) * gw + x] = m;
+            }
+        for (uint32_t item : geometric) item_cost[item] = grid[cell_of(item)];
+    }
+    // Tiles above the threshold are split into four 4x4 quarter tiles marched depth-parallel (raymarch_pq.h): their cost is
+    // a long chain of dependent samples, which four lanes per ray walk ~4x faster, on four waves.  Which tiles?  Those that
+    // would keep one wave busy for more than ~1.5x a wave's fair share of the frame (sum of costs / resident waves): below
+    // that they hide in the bulk and splitting only adds work.  A tile that is split stays split until its estimated cost
+    // falls below 0.7x the threshold (its cost is an estimate while it is split).
+    uint64_t total_cost = 0;
+    for (uint32_t item : geometric) total_cost += item_cost[item];
+    const uint32_t resident_waves = std::max(1u, job.max_grid * waves);
+    // measured optimum: 1.5x for the table mode, 1.2x for the continuous-rho modes (their classic loop speculates only two
+    // samples deep, a depth-parallel item four)
+    const uint64_t tenths = job.dp_min_cost < -1 ? static_cast<uint64_t>(-job.dp_min_cost) : (job.continuous ? 12u : 15u);
+    const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(64, tenths * total_cost / (10u * resident_waves) + 16));
+    const uint32_t dp_thr = job.dp_min_cost < 0 ? adaptive : static_cast<uint32_t>(job.dp_min_cost);
+    const bool dp_ok = job.dp_min_cost != 0;
+    std::vector<std::pair<uint32_t, uint32_t>> keyed;      // (cost share, entry)
+    keyed.reserve(geometric.size() * 2);
+    // 16x16 tiles whose four sub-tiles were all constant become one "super" fill item (bit 30)
+    std::vector<uint8_t> all_fill(n_local, 1), seen(n_local, 0), cnt(n_local, 0);
+    for (uint32_t item : geometric) { if (item_cost[item] != 0) all_fill[item >> 2] = 0; cnt[item >> 2]++; }
+    for (uint32_t lt = 0; lt < n_local; ++lt) if (cnt[lt] != 4) all_fill[lt] = 0;   // sub-tiles outside the frame are not listed
+    for (uint32_t item : geometric) {
+        const uint32_t k = item_cost[item];
+        if (job.super_fill && all_fill[item >> 2]) {
+            if (!seen[item >> 2]) { seen[item >> 2] = 1; keyed.emplace_back(0u, 0x40000000u | (item >> 2)); }
+            item_is_dp[item] = 0;
+            continue;
+        }
+        const bool split = dp_ok && (k >= dp_thr || (item_is_dp[item] && job.dp_min_cost < 0 && 10u * k >= 7u * dp_thr));
+        item_is_dp[item] = split ? 1 : 0;
+        if (split)
+            for (uint32_t qd = 0; qd < 4; ++qd) keyed.emplace_back((k * job.dp_share_pct + 99u) / 100u, 0x80000000u | (item << 2) | qd);
+        else
+            keyed.emplace_back(k, item);
+    }
+    {
+        // stable counting sort by decreasing cost share (shares are small integers): the feedback thread's latency is what
+        // a moving camera sees as the age of its list
+        uint32_t kmax = 0;
+        for (const auto& kv : keyed) kmax = std::max(kmax, kv.first);
+        std::vector<uint32_t> start(static_cast<size_t>(kmax) + 2u, 0);
+        for (const auto& kv : keyed) start[kmax - kv.first + 1u]++;
+        for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
+        std::vector<std::pair<uint32_t, uint32_t>> sorted(keyed.size());
+        for (const auto& kv : keyed) sorted[start[kmax - kv.first]++] = kv;
+        keyed.swap(sorted);
+    }
+    if (job.only_quarters) {     // dev experiment: how long do the depth-parallel items take with the machine to themselves?
+        std::vector<std::pair<uint32_t, uint32_t>> q;
+        for (const auto& kv : keyed) if (kv.second >> 31) q.push_back(kv);
+        keyed.swap(q);
+    }
+    // issue priority (bits 28-29) from the entry's cost relative to a wave's fair share of the frame
+    const uint64_t fair = std::max<uint64_t>(1, total_cost / resident_waves);
+    const bool prio_ok = job.prio_tenths[0] > 0 && static_cast<uint64_t>(n_local) * 16u < (1u << 28);
+    const uint32_t n_keyed = static_cast<uint32_t>(keyed.size());
+    const uint32_t G = std::max(1u, std::min((n_keyed + waves - 1) / waves, job.max_grid));
+    // Workgroup b reads entries b, b + G, ... of the list.  The entries, in order of decreasing cost, are dealt in
+    // boustrophedon order over the workgroups (0..G-1, G-1..0, ...): the sums differ by about one entry of the current size,
+    // as with a longest-processing-time heap, in one pass (the feedback thread's latency is the age of a moving camera's
+    // list).  Rounds are list rows: entry i sits in row i / G.
+    const size_t rows = (static_cast<size_t>(n_keyed) + G - 1) / G;
+    out.entries.assign(static_cast<size_t>(G) * rows, PQ_NO_ITEM);
+    for (uint32_t i = 0; i < n_keyed; ++i) {
+        const std::pair<uint32_t, uint32_t>& kv = keyed[i];
+        uint32_t prio = 0;
+        if (prio_ok && kv.first) {
+            const uint64_t k10 = static_cast<uint64_t>(kv.first) * 10u;
+            prio = k10 >= job.prio_tenths[2] * fair ? 3u : k10 >= job.prio_tenths[1] * fair ? 2u : k10 >= job.prio_tenths[0] * fair ? 1u : 0u;
+        }
+        const uint32_t row = i / G, j = i - row * G;
+        out.entries[static_cast<size_t>(row) * G + ((row & 1u) ? G - 1u - j : j)] = kv.second | (prio << 28);
+    }
+    out.grid = G;
+    out.view_serial = job.view_serial;
+    (void)c;
+}
+
+// costs by list position -> costs by item
+static void costs_to_items(const WorkList& list, const uint16_t* cost, uint32_t n_entries, std::vector<uint16_t>& item_cost)
+{
+    std::vector<uint32_t> q_max(item_cost.size(), 0);
+    std::vector<uint8_t> q_seen(item_cost.size(), 0);
+    for (uint32_t p = 0; p < n_entries && p < list.entries.size(); ++p) {
+        const uint32_t raw_p = list.entries[p];
+        if (raw_p == PQ_NO_ITEM) continue;
+        const uint32_t raw = raw_p & ~0x30000000u;
+        const uint32_t k = cost[p];
+        if (raw >> 31) {                                   // depth-parallel quarter: the tile's cost is 5 + the slowest quarter
+            const uint32_t item = (raw & 0x7fffffffu) >> 2;
+            if (item < item_cost.size()) { q_max[item] = std::max(q_max[item], k); q_seen[item] = 1; }
+        } else if ((raw >> 30) == 1u) {                    // super fill: zero, or the sum of four marched sub-tiles
+            const uint32_t lt = raw & 0x3fffffffu;
+            for (uint32_t sub = 0; sub < 4; ++sub)
+                if (lt * 4u + sub < item_cost.size()) item_cost[lt * 4u + sub] = static_cast<uint16_t>(k == 0 ? 0u : std::max(1u, k / 4u));
+        } else if (raw < item_cost.size()) {
+            item_cost[raw] = static_cast<uint16_t>(k);
+        }
+    }
+    for (size_t i = 0; i < item_cost.size(); ++i)
+        if (q_seen[i]) item_cost[i] = static_cast<uint16_t>(std::min(65535u, 5u + q_max[i]));
+}
+
+static void feedback_thread(volym_ctx* c)
+{
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(c->fb_mu);
+            c->fb_cv.wait(lk, [&] { const int s = c->fb_state.load(std::memory_order_acquire); return s == volym_ctx::FB_CAPTURED || s == volym_ctx::FB_QUIT; });
+        }
+        if (c->fb_state.load(std::memory_order_acquire) == volym_ctx::FB_QUIT) return;
+        volym_ctx::FbJob& job = c->fb_job;
+        job.error.clear();
+        auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        job.t_us[1] = now_us();
+        hipError_t e = hipEventSynchronize(c->ev_cost);            // the captured launch and its cost copy are done
+        job.t_us[2] = now_us();
+        const int next = job.list ^ 1;
+        if (e == hipSuccess) {
+            costs_to_items(c->lists[job.list], c->h_cost_pinned, job.n_entries, c->item_cost);
+            job.t_us[3] = now_us();
+            deal_list(c, job, c->item_cost, c->item_is_dp, c->geometric, c->n_local, c->lists[next]);
+            job.t_us[4] = now_us();
+            if (c->lists[next].entries.size() > c->list_capacity) {
+                job.error = "work list larger than its buffers";    // cannot happen: capacity is the worst case
+            } else {
+                std::memcpy(c->h_list_pinned, c->lists[next].entries.data(), c->lists[next].entries.size() * sizeof(uint32_t));
+                // every launch that read d_list[next] finished before the captured launch did (same stream, in order)
+                e = hipMemcpyAsync(c->d_list[next], c->h_list_pinned, c->lists[next].entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream);
+                if (e == hipSuccess) e = hipEventRecord(c->ev_list, c->copy_stream);
+                if (e == hipSuccess) e = hipEventSynchronize(c->ev_list);
+            }
+        }
+        if (e != hipSuccess) job.error = std::string("cost feedback: ") + hipGetErrorString(e);
+        job.t_us[5] = now_us();
+        c->fb_state.store(volym_ctx::FB_READY, std::memory_order_release);
+        c->fb_cv.notify_all();
+    }
+}
+
+// caller side: adopt a finished list (never blocks)
+static void feedback_poll(volym_ctx* c)
+{
+    if (c->fb_state.load(std::memory_order_acquire) != volym_ctx::FB_READY) return;
+    if (c->fb_job.error.empty()) c->cur = c->fb_job.list ^ 1;
+    c->fb_state.store(volym_ctx::FB_IDLE, std::memory_order_release);
+}
+
+// caller side, blocking (set-up calls, volym_settle): wait for a job in flight and adopt its list
+static void feedback_quiesce(volym_ctx* c)
+{
+    if (c->fb_state.load(std::memory_order_acquire) == volym_ctx::FB_CAPTURED) {
+        std::unique_lock<std::mutex> lk(c->fb_mu);
+        c->fb_cv.wait(lk, [&] { return c->fb_state.load(std::memory_order_acquire) != volym_ctx::FB_CAPTURED; });
+    }
+    feedback_poll(c);
+}
+
+// (Re)build the lists of this shard: geometric order, no costs.  Blocking set-up path (create, set_shard, options).
+static int rebuild_lists(volym_ctx* c)
+{
+    feedback_quiesce(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    build_geometric(c);
+    // worst case: every 8x8 item split into four quarters, plus padding to a multiple of the grid
+    const size_t need = static_cast<size_t>(c->n_local) * 16u + 2u * static_cast<size_t>(c->n_cus) * 8u + 64u;
+    if (need > c->list_capacity) {
+        for (int i = 0; i < 2; ++i) { if (c->d_list[i]) (void)hipFree(c->d_list[i]); c->d_list[i] = nullptr; }
+        if (c->d_cost) (void)hipFree(c->d_cost);
+        if (c->h_list_pinned) (void)hipHostFree(c->h_list_pinned);
+        if (c->h_cost_pinned) (void)hipHostFree(c->h_cost_pinned);
+        c->d_cost = nullptr; c->h_list_pinned = nullptr; c->h_cost_pinned = nullptr; c->list_capacity = 0;
+        hipError_t e = hipMalloc(&c->d_list[0], need * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&c->d_list[1], need * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&c->d_cost, need * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipHostMalloc(&c->h_list_pinned, need * sizeof(uint32_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(&c->h_cost_pinned, need * sizeof(uint16_t), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("work lists: ") + hipGetErrorString(e));
+        c->list_capacity = need;
+    }
+    c->item_cost.assign(static_cast<size_t>(c->n_local) * 4, 0);
+    c->item_is_dp.assign(static_cast<size_t>(c->n_local) * 4, 0);
+    c->cur = 0;
+    c->lists[0].entries = c->geometric;
+    c->lists[0].grid = 0;
+    c->lists[0].view_serial = 0;
+    c->lists[1] = WorkList();
+    if (!c->geometric.empty())
+        HIPCHK(c, hipMemcpy(c->d_list[0], c->geometric.data(), c->geometric.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->lists_ready = true;
+    return VOLYM_OK;
+}
+
+// costs no longer describe the scene (new volume, transfer function, threshold grid...): back to the geometric order
+static int forget_costs(volym_ctx* c)
+{
+    if (!c->lists_ready) return VOLYM_OK;
+    return rebuild_lists(c);
+}
+
+// Macro-cell maxima, their host copy and the occupied-cell AABB for every threshold byte (set-up path: blocks).
+static int build_macro_cells(volym_ctx* c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_mc) { HIPCHK(c, hipFree(c->d_mc)); c->d_mc = nullptr; }
+    if (c->d_df) { HIPCHK(c, hipFree(c->d_df)); c->d_df = nullptr; }
+    const uint32_t n = c->mc_n, cells = n * n * n;
+    hipError_t e = hipMalloc(&c->d_mc, cells);
+    if (e == hipSuccess) e = hipMalloc(&c->d_df, (cells / 2u + 15u) / 16u * 16u);
+    if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(macro cells): ") + hipGetErrorString(e));
+    hipLaunchKernelGGL(volym_macrocell_kernel, dim3(cells), dim3(256), 0, c->stream, c->d_vol, c->d_mc, c->nx, c->ny, c->nz, c->mc_n, c->bricked ? 1u : 0u);
+    HIPCHK(c, hipGetLastError());
+    c->h_mc.resize(cells);
+    HIPCHK(c, hipMemcpyAsync(c->h_mc.data(), c->d_mc, cells, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // AABB of the cells whose maximum reaches b, for every b: boxes of the cells with maximum exactly v, then a suffix union
+    int box[257][6];
+    for (int v = 0; v <= 256; ++v) { box[v][0] = box[v][1] = box[v][2] = 1 << 30; box[v][3] = box[v][4] = box[v][5] = -1; }
+    for (uint32_t z = 0; z < n; ++z)
+        for (uint32_t y = 0; y < n; ++y)
+            for (uint32_t x = 0; x < n; ++x) {
+                int* b = box[c->h_mc[(z * n + y) * n + x]];
+                const int p[3] = {static_cast<int>(x), static_cast<int>(y), static_cast<int>(z)};
+                for (int i = 0; i < 3; ++i) { b[i] = std::min(b[i], p[i]); b[3 + i] = std::max(b[3 + i], p[i]); }
+            }
+    int run[6] = {1 << 30, 1 << 30, 1 << 30, -1, -1, -1};
+    for (int i = 0; i < 6; ++i) c->aabb_tab[256][i] = i < 3 ? 0 : -1;         // threshold byte 256: nothing is dense
+    for (int v = 255; v >= 0; --v) {
+        for (int i = 0; i < 3; ++i) { run[i] = std::min(run[i], box[v][i]); run[3 + i] = std::max(run[3 + i], box[v][3 + i]); }
+        for (int i = 0; i < 6; ++i) c->aabb_tab[v][i] = run[3] < 0 ? (i < 3 ? 0 : -1) : run[i];
+    }
+    c->df_thr_byte = 0xffffffffu;
+    c->hull_dirty = true;
+    return VOLYM_OK;
+}
+
+extern "C" {
+
+int volym_abi_version(void) { return VOLYM_ABI_VERSION; }
+
+const char* volym_last_error(const volym_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int volym_create(volym_ctx** out, uint32_t width, uint32_t height, int device_id)
+{
+    if (!out) return fail(nullptr, VOLYM_E_INVALID, "volym_create: out is NULL");
+    *out = nullptr;
+    if (width == 0 || height == 0 || width > 32768 || height > 32768)
+        return fail(nullptr, VOLYM_E_INVALID, "volym_create: viewport must be 1..32768 in each dimension");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(nullptr, VOLYM_E_NO_DEVICE, "volym_create: no HIP device visible");
+    int dev = device_id;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= n_dev) return fail(nullptr, VOLYM_E_NO_DEVICE, "volym_create: device_id out of range");
+    hipDeviceProp_t prop;
+    HIPCHK(nullptr, hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, VOLYM_E_NO_DEVICE,
+                    std::string("volym_create: this library carries gfx950 code only, device is ") + prop.gcnArchName);
+    HIPCHK(nullptr, hipSetDevice(dev));
+
+    volym_ctx* c = new (std::nothrow) volym_ctx();
+    if (!c) return fail(nullptr, VOLYM_E_NOMEM, "volym_create: out of host memory");
+    c->device = dev;
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->W = width; c->H = height;
+    c->tiles_x = (width + 15u) / 16u;     // src/demos/pipeline.rs:83-87
+    c->tiles_y = (height + 15u) / 16u;
+    c->n_tiles = c->tiles_x * c->tiles_y;
+    recompute_shard(c);
+    std::memset(&c->fp, 0, sizeof c->fp);
+    std::memset(&c->tables_now, 0, sizeof c->tables_now);
+    std::memset(c->aabb_tab, 0, sizeof c->aabb_tab);
+
+    auto bail = [&](hipError_t e, const char* what) {
+        std::string m = std::string(what) + ": " + hipGetErrorString(e);
+        volym_destroy(c);
+        return fail(nullptr, e == hipErrorOutOfMemory ? VOLYM_E_NOMEM : VOLYM_E_HIP, m);
+    };
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    c->stream = c->own_stream;
+    const size_t frame_bytes = static_cast<size_t>(width) * height * 4;
+    if ((e = hipMalloc(&c->d_frame_own, frame_bytes)) != hipSuccess) return bail(e, "hipMalloc(frame)");
+    if ((e = hipMalloc(&c->d_shard_own, static_cast<size_t>(c->n_tiles) * 1024)) != hipSuccess) return bail(e, "hipMalloc(shard)");
+    if ((e = hipMalloc(&c->d_tables, sizeof(FrameTables))) != hipSuccess) return bail(e, "hipMalloc(tables)");
+    if ((e = hipMalloc(&c->d_counters, sizeof(Counters))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMemset(c->d_frame_own, 0, frame_bytes)) != hipSuccess) return bail(e, "hipMemset(frame)");
+    if ((e = hipMalloc(&c->d_aabb, 6 * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(aabb)");
+    if ((e = hipMalloc(&c->d_pack_counters, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pack counters)");
+    if ((e = hipMemset(c->d_pack_counters, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMemset(pack counters)");
+    for (int i = 0; i < volym_ctx::TABLE_RING; ++i) {
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_tables[i]), sizeof(FrameTables), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(tables)");
+        if ((e = hipEventCreateWithFlags(&c->tables_ev[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    }
+    if ((e = hipEventCreateWithFlags(&c->ev_march, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->ev_list, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+
+    c->d_frame = c->d_frame_own;
+    c->d_shard = c->d_shard_own;
+    int rc = rebuild_lists(c);
+    if (rc != VOLYM_OK) { const std::string m = c->err; volym_destroy(c); return fail(nullptr, rc, m); }
+    try {
+        c->fb_thread = std::thread(feedback_thread, c);
+    } catch (...) {
+        volym_destroy(c);
+        return fail(nullptr, VOLYM_E_NOMEM, "volym_create: cannot start the feedback thread");
+    }
+    *out = c;
+    return VOLYM_OK;
+}
+
+void volym_destroy(volym_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->fb_thread.joinable()) {
+        feedback_quiesce(c);
+        {
+            std::lock_guard<std::mutex> lk(c->fb_mu);
+            c->fb_state.store(volym_ctx::FB_QUIT, std::memory_order_release);
+        }
+        c->fb_cv.notify_all();
+        c->fb_thread.join();
+    }
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipFree(c->d_vol); (void)hipFree(c->d_imp); (void)hipFree(c->d_tables); (void)hipFree(c->d_mc); (void)hipFree(c->d_df);
+    (void)hipFree(c->d_shard_own); (void)hipFree(c->d_frame_own); (void)hipFree(c->d_f32); (void)hipFree(c->d_blit);
+    (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_pack_counters); (void)hipFree(c->d_counters); (void)hipFree(c->d_aabb);
+    (void)hipFree(c->d_list[0]); (void)hipFree(c->d_list[1]); (void)hipFree(c->d_cost);
+    if (c->h_list_pinned) (void)hipHostFree(c->h_list_pinned);
+    if (c->h_cost_pinned) (void)hipHostFree(c->h_cost_pinned);
+    for (int i = 0; i < volym_ctx::TABLE_RING; ++i) {
+        if (c->h_tables[i]) (void)hipHostFree(c->h_tables[i]);
+        if (c->tables_ev[i]) (void)hipEventDestroy(c->tables_ev[i]);
+    }
+    for (uint32_t i = 0; i < volym_ctx::THROTTLE_RING; ++i) if (c->throttle_ev[i]) (void)hipEventDestroy(c->throttle_ev[i]);
+    if (c->ev_march) (void)hipEventDestroy(c->ev_march);
+    if (c->ev_cost) (void)hipEventDestroy(c->ev_cost);
+    if (c->ev_list) (void)hipEventDestroy(c->ev_list);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    delete c;
+}
+
+int volym_set_stream(volym_ctx* c, void* hip_stream)
+{
+    if (!c) return VOLYM_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    feedback_quiesce(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return VOLYM_OK;
+}
+
+int volym_settle(volym_ctx* c)
+{
+    if (!c) return VOLYM_E_INVALID;
+    feedback_quiesce(c);
+    if (!c->fb_job.error.empty()) { const std::string m = c->fb_job.error; c->fb_job.error.clear(); return fail(c, VOLYM_E_HIP, m); }
+    return VOLYM_OK;
+}
+
+static bool want_bricked(const volym_ctx* c, uint32_t nx, uint32_t ny, uint32_t nz);
+
+int volym_set_option(volym_ctx* c, int key, int value)
+{
+    if (!c) return VOLYM_E_INVALID;
+    switch (key) {
+    case VOLYM_OPT_KERNEL:
+        if (value < 0 || value > 2) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_KERNEL: 0 (direct), 1 (macro-cell) or 2 (persistent + shading queue)");
+        c->kernel_variant = value;
+        return VOLYM_OK;
+    case VOLYM_OPT_WRITE_F32:
+        c->write_f32 = value != 0;
+        if (c->write_f32 && !c->d_f32) {
+            HIPCHK(c, hipSetDevice(c->device));
+            hipError_t e = hipMalloc(&c->d_f32, static_cast<size_t>(c->W) * c->H * sizeof(float4));
+            if (e != hipSuccess) { c->write_f32 = false; return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(f32 frame): ") + hipGetErrorString(e)); }
+        }
+        return VOLYM_OK;
+    case VOLYM_OPT_MACRO_CELLS:
+        if (value < 4 || value > 32 || (value & (value - 1)) != 0)
+            return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_MACRO_CELLS: power of two in 4..32");
+        c->mc_n = static_cast<uint32_t>(value);
+        if (c->have_vol) { int rc = build_macro_cells(c); if (rc != VOLYM_OK) return rc; }
+        return forget_costs(c);
+    case VOLYM_OPT_VOLUME_LAYOUT:
+        if (value < -1 || value > 1) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_VOLUME_LAYOUT: -1 (by size), 0 (linear) or 1 (4x4x4 bricks)");
+        c->layout_choice = value;
+        return VOLYM_OK;
+    case VOLYM_OPT_CULLING:
+        c->culling = value != 0;
+        c->hull_dirty = true;
+        return VOLYM_OK;
+    case VOLYM_OPT_COST_FEEDBACK:
+        c->feedback = value != 0;
+        return forget_costs(c);
+    case VOLYM_OPT_DEPTH_PARALLEL:
+        if (value < -100 || value > 65535) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_DEPTH_PARALLEL: < 0 adaptive (-N = N/10 x fair share), 0 off, else explicit cost");
+        c->dp_min_cost = value;
+        return forget_costs(c);
+    case VOLYM_OPT_XCD_BANDS:
+        if (value < 0 || value > 64) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_XCD_BANDS: 0..64");
+        c->xcd_bands = static_cast<uint32_t>(value);
+        return VOLYM_OK;
+#if VOLYM_DEV_SWITCHES
+    // tuning knobs of the development build (make DEV=1; scripts/ablate.py)
+    case 101:   // persistent workgroups per CU (variant 2)
+        if (value < 1 || value > 8) return fail(c, VOLYM_E_INVALID, "workgroups per CU: 1..8");
+        c->wgs_per_cu = static_cast<uint32_t>(value);
+        return forget_costs(c);
+    case 107:   // 0 disables the 16x16 super fill items
+        c->super_fill = value != 0;
+        return forget_costs(c);
+    case 108:   // issue-priority thresholds t1 + 100*t2 + 10000*t3 in tenths of the fair share (0 = no priorities)
+        if (value < 0) return fail(c, VOLYM_E_INVALID, "priority thresholds: t1 + 100*t2 + 10000*t3, tenths of the fair share");
+        c->prio_tenths[0] = static_cast<uint32_t>(value % 100);
+        c->prio_tenths[1] = static_cast<uint32_t>((value / 100) % 100);
+        c->prio_tenths[2] = static_cast<uint32_t>(value / 10000);
+        return forget_costs(c);
+    case 109:   // keep only the depth-parallel items in the work list (the frame is then incomplete)
+        c->dev_only_quarters = value != 0;
+        return forget_costs(c);
+    case 110:   // FrameParams::dev
+        c->fp.dev = static_cast<uint32_t>(value);
+        return VOLYM_OK;
+    case 113:   // 1 freezes the cost feedback: no more captures, the current list stays (how fast do lists go stale?)
+        feedback_quiesce(c);
+        c->feedback_frozen = value != 0;
+        return VOLYM_OK;
+    case 114:   // dilation radius (in 8x8 items) of the cost map when a list is dealt
+        c->cost_dilate = std::max(-1, std::min(value, 4));
+        return VOLYM_OK;
+    case 111:   // balancing estimates, dp_share_pct + 1000 * fill_cost
+        c->dp_share_pct = static_cast<uint32_t>(value % 1000);
+        c->fill_cost = static_cast<uint32_t>(value / 1000);
+        return forget_costs(c);
+#endif
+    default:
+        return fail(c, VOLYM_E_INVALID, "volym_set_option: unknown key");
+    }
+}
+
+int volym_set_shard(volym_ctx* c, uint32_t rank, uint32_t world)
+{
+    if (!c) return VOLYM_E_INVALID;
+    if (world == 0 || rank >= world || world > 4096) return fail(c, VOLYM_E_INVALID, "volym_set_shard: need rank < world <= 4096");
+    c->rank = rank; c->world = world;
+    recompute_shard(c);
+    return rebuild_lists(c);
+}
+
+static int upload_volume(volym_ctx* c, uint8_t** dst, const uint8_t* src, uint32_t nx, uint32_t ny, uint32_t nz)
+{
+    const bool bricked = want_bricked(c, nx, ny, nz);
+    if (!src || nx == 0 || ny == 0 || nz == 0) return fail(c, VOLYM_E_INVALID, "volume: NULL data or zero dimension");
+    const uint64_t n = static_cast<uint64_t>(nx) * ny * nz;
+    const uint64_t nb = bricked ? static_cast<uint64_t>(brick_count(nx)) * brick_count(ny) * brick_count(nz) * 64u : n;
+    if (nx > 4096 || ny > 4096 || nz > 4096 || nb > 0xffffffffull)
+        return fail(c, VOLYM_E_INVALID, "volume: each dimension <= 4096 and the brick-padded size < 2^32");
+    HIPCHK(c, hipSetDevice(c->device));
+    feedback_quiesce(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (*dst) { HIPCHK(c, hipFree(*dst)); *dst = nullptr; }
+    uint8_t* staging = nullptr;
+    hipError_t e = hipMalloc(dst, nb + 16);      // the trilinear fetch reads voxel pairs: one byte past the last voxel is touched
+    if (e == hipSuccess) e = hipMemset(*dst + nb, 0, 16);
+    if (e == hipSuccess && bricked) e = hipMalloc(&staging, n);
+    if (e != hipSuccess) { (void)hipFree(staging); return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(volume): ") + hipGetErrorString(e)); }
+    e = hipMemcpy(bricked ? staging : *dst, src, n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && bricked) {
+        hipLaunchKernelGGL(volym_rebrick_kernel, dim3(static_cast<uint32_t>((nb + 255u) / 256u)), dim3(256), 0, c->stream, staging, *dst, nx, ny, nz);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(staging);
+    if (e != hipSuccess) return fail(c, VOLYM_E_HIP, std::string("volume upload: ") + hipGetErrorString(e));
+    return VOLYM_OK;
+}
+
+// Bricks pay once the volume outgrows the L2s (measured: from 512^3 on; see raymarch_device.h); volume and importances of
+// the same dimensions get the same answer.
+static bool want_bricked(const volym_ctx* c, uint32_t nx, uint32_t ny, uint32_t nz)
+{
+    if (c->layout_choice >= 0) return c->layout_choice == 1;
+    return static_cast<uint64_t>(nx) * ny * nz > c->brick_from_bytes;
+}
+
+int volym_set_volume(volym_ctx* c, const uint8_t* voxels, uint32_t nx, uint32_t ny, uint32_t nz, int filter)
+{
+    if (!c) return VOLYM_E_INVALID;
+    if (filter != VOLYM_FILTER_NEAREST && filter != VOLYM_FILTER_LINEAR)
+        return fail(c, VOLYM_E_INVALID, "volym_set_volume: filter must be VOLYM_FILTER_NEAREST or VOLYM_FILTER_LINEAR");
+    int rc = upload_volume(c, &c->d_vol, voxels, nx, ny, nz);
+    if (rc != VOLYM_OK) { c->have_vol = false; return rc; }
+    c->nx = nx; c->ny = ny; c->nz = nz; c->filter = filter;
+    c->bricked = want_bricked(c, nx, ny, nz);
+    c->have_vol = true;
+    rc = build_macro_cells(c);
+    if (rc != VOLYM_OK) { c->have_vol = false; return rc; }
+    return forget_costs(c);
+}
+
+int volym_set_importances(volym_ctx* c, const uint8_t* importances, uint32_t nx, uint32_t ny, uint32_t nz)
+{
+    if (!c) return VOLYM_E_INVALID;
+    int rc = upload_volume(c, &c->d_imp, importances, nx, ny, nz);
+    if (rc != VOLYM_OK) { c->have_imp = false; return rc; }
+    c->inx = nx; c->iny = ny; c->inz = nz;
+    c->have_imp = true;
+    return forget_costs(c);
+}
+
+int volym_set_transfer_function(volym_ctx* c, const uint8_t* rgba8, uint32_t n)
+{
+    if (!c) return VOLYM_E_INVALID;
+    if (!rgba8 || n < 1 || n > 256) return fail(c, VOLYM_E_INVALID, "volym_set_transfer_function: 1..256 RGBA8 texels");
+    std::memset(c->lut, 0, sizeof c->lut);
+    std::memcpy(c->lut, rgba8, static_cast<size_t>(n) * 4);
+    c->tf_n = n;
+    c->have_tf = true;
+    c->tables_dirty = true;
+    return VOLYM_OK;
+}
+
+}  // extern "C"
+
+// Per-frame resources that depend on the uniforms: distance field for the threshold byte (a launch, in stream order) and
+// the culling hulls (host arithmetic).  Nothing here allocates or waits.
 static int ensure_frame_resources(volym_ctx* c)
 {
-    if (c->order_dirty) {
-        int rc = build_order(c);
-        if (rc != VOLYM_OK) return rc;
-    }
-    if (c->write_f32 && !c->d_f32) {
-        hipError_t e = hipMalloc(&c->d_f32, static_cast<size_t>(c->W) * c->H * sizeof(float4));
-        if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(f32 frame): ") + hipGetErrorString(e));
-    }
-    if (c->mc_dirty || c->mc_built_n != c->mc_n) {
-        if (c->d_mc) { HIPCHK(c, hipFree(c->d_mc)); c->d_mc = nullptr; }
-        if (c->d_df) { HIPCHK(c, hipFree(c->d_df)); c->d_df = nullptr; }
-        const uint32_t cells = c->mc_n * c->mc_n * c->mc_n;
-        hipError_t e = hipMalloc(&c->d_mc, cells);
-        if (e == hipSuccess) e = hipMalloc(&c->d_df, (cells / 2u + 15u) / 16u * 16u);
-        if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(macro cells): ") + hipGetErrorString(e));
-        hipLaunchKernelGGL(volym_macrocell_kernel, dim3(cells), dim3(256), 0, c->stream, c->d_vol, c->d_mc, c->nx, c->ny, c->nz, c->mc_n, c->bricked ? 1u : 0u);
-        HIPCHK(c, hipGetLastError());
-        c->mc_dirty = false;
-        c->mc_built_n = c->mc_n;
-        c->df_thr_byte = 0xffffffffu;
-    }
     if (c->df_thr_byte != c->thr_byte_cull) {
         // stream order: earlier frames finish reading d_df before this kernel rewrites it
         hipLaunchKernelGGL(volym_distance_field_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_mc, c->d_df, c->d_aabb, c->mc_n, c->thr_byte_cull);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(c->h_aabb, c->d_aabb, sizeof c->h_aabb, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));   // only when volume / threshold / grid changed
         c->df_thr_byte = c->thr_byte_cull;
         c->hull_dirty = true;
     }
@@ -743,30 +861,36 @@ int volym_update(volym_ctx* c, const volym_camera_uniforms* cam, const volym_par
     std::memcpy(fp.cone_sin, k_cone_sin, sizeof k_cone_sin);
 
     if (c->tables_dirty || c->tables_alpha_y != fp.alpha_y) {
-        build_tables(c, fp.alpha_y);
-        HIPCHK(c, hipStreamSynchronize(c->stream));   // the previous frame may still read d_tables
-        HIPCHK(c, hipMemcpy(c->d_tables, &c->h_tables, sizeof(FrameTables), hipMemcpyHostToDevice));
+        // New tables travel in stream order behind the frames that read the old ones.  The pinned staging slot must not be
+        // rewritten before its copy has run: a ring of TABLE_RING slots, each with the event of its last copy.  Only a
+        // caller that changes the step size or the transfer function TABLE_RING times while the device is that many frames
+        // behind ever waits here.
+        const int slot = c->tables_slot;
+        c->tables_slot = (slot + 1) % volym_ctx::TABLE_RING;
+        if (hipEventQuery(c->tables_ev[slot]) != hipSuccess) HIPCHK(c, hipEventSynchronize(c->tables_ev[slot]));
+        build_tables(c, *c->h_tables[slot], fp.alpha_y);
+        c->tables_now = *c->h_tables[slot];
+        HIPCHK(c, hipMemcpyAsync(c->d_tables, c->h_tables[slot], sizeof(FrameTables), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->tables_ev[slot], c->stream));
         c->tables_dirty = false;
         c->tables_alpha_y = fp.alpha_y;
     }
     uint32_t tb = 256;
     for (int b = 255; b >= 0; --b)
-        if (c->h_tables.rho[b] >= fp.thr) tb = static_cast<uint32_t>(b); else break;
+        if (c->tables_now.rho[b] >= fp.thr) tb = static_cast<uint32_t>(b); else break;
     fp.thr_byte = tb;
     // continuous-rho modes (trilinear / smoothed) compare an interpolated value: give its rounding some room
     if (fp.flags & (F_LINEAR | F_GAUSSIAN)) {
         const float cons = fp.thr - std::fabs(fp.thr) * 1.0e-5f - 1.0e-7f;
         uint32_t tc = 256;
         for (int b = 255; b >= 0; --b)
-            if (c->h_tables.rho[b] >= cons) tc = static_cast<uint32_t>(b); else break;
+            if (c->tables_now.rho[b] >= cons) tc = static_cast<uint32_t>(b); else break;
         c->thr_byte_cull = tc;
     } else {
         c->thr_byte_cull = tb;
     }
-    if (!c->have_frame || std::memcmp(&c->cam_copy, cam, sizeof *cam) != 0 || std::memcmp(&c->par_copy, par, sizeof *par) != 0) {
-        c->frames_since_change = 0;          // the measured costs describe another view
-        if (c->order_by_cost) c->order_dirty = true;   // back to the geometric order until re-measured
-    }
+    if (!c->have_frame || std::memcmp(&c->cam_copy, cam, sizeof *cam) != 0 || std::memcmp(&c->par_copy, par, sizeof *par) != 0)
+        c->view_serial.fetch_add(1, std::memory_order_relaxed);   // the lists stay valid (they are scheduling only); the feedback follows the view
     c->cam_copy = *cam;
     c->par_copy = *par;
     c->hull_dirty = true;
@@ -797,20 +921,20 @@ static int launch_march(volym_ctx* c)
     Counters* cnt = COUNT ? c->d_counters : nullptr;
     uint4* trace = TRACE ? c->d_trace : nullptr;
     if (c->kernel_variant == 2) {
-        if (c->n_items == 0) return VOLYM_OK;
         const bool plain = !COUNT && !TRACE;
-        if (plain && c->feedback && !c->order_by_cost && c->frames_since_change == 1) {
-            int rcc = reorder_by_cost(c);
-            if (rcc != VOLYM_OK) return rcc;
-        }
-        uint16_t* cost_out = (plain && c->feedback && !c->order_by_cost) ? c->d_cost : nullptr;
-        if (plain) c->frames_since_change++;
-        const uint32_t want = (c->n_items + PQ_WAVES - 1) / PQ_WAVES;
-        const uint32_t pgrid = c->order_grid ? c->order_grid : std::max(1u, std::min(want, static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu));
+        if (plain) feedback_poll(c);                      // adopt a list the feedback thread has finished
+        const WorkList& wl = c->lists[c->cur];
+        const uint32_t n_items = static_cast<uint32_t>(wl.entries.size());
+        if (n_items == 0) return VOLYM_OK;
+        // capture this launch's costs?  Only one capture is in flight; a list measured on this very view is final
+        const bool capture = plain && c->feedback && !c->feedback_frozen && c->fb_state.load(std::memory_order_acquire) == volym_ctx::FB_IDLE && wl.view_serial != c->view_serial.load(std::memory_order_relaxed);
+        uint16_t* cost_out = capture ? c->d_cost : nullptr;
+        const uint32_t want = (n_items + PQ_WAVES - 1) / PQ_WAVES;
+        const uint32_t pgrid = wl.grid ? wl.grid : std::max(1u, std::min(want, max_grid(c)));
         const bool table = !(fp.flags & (F_LINEAR | F_GAUSSIAN));
 #define VOLYM_PQ_LAUNCH(T, KS, I, B, R)                                                                                          \
     hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT && I, TRACE, KS, I, B, R>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,  \
-                       c->d_imp, c->d_tables, c->d_df, c->d_order, c->n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
+                       c->d_imp, c->d_tables, c->d_df, c->d_list[c->cur], n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
         // IMP = false: opacity on and no importance colouring (the common cases), without (IR = false) or with (IR = true)
         // importance rendering; the instrumented launch always takes the general form
         const bool special = !COUNT && !(fp.flags & F_IMP_COLORING) && (fp.flags & F_OPACITY);
@@ -829,6 +953,33 @@ static int launch_march(volym_ctx* c)
         }
 #undef VOLYM_PQ_LAUNCH
         HIPCHK(c, hipGetLastError());
+        if (capture) {
+            // costs -> pinned host memory on the copy stream, behind this launch; the feedback thread takes it from there
+            HIPCHK(c, hipEventRecord(c->ev_march, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_march, 0));
+            HIPCHK(c, hipMemcpyAsync(c->h_cost_pinned, c->d_cost, static_cast<size_t>(n_items) * sizeof(uint16_t), hipMemcpyDeviceToHost, c->copy_stream));
+            HIPCHK(c, hipEventRecord(c->ev_cost, c->copy_stream));
+            volym_ctx::FbJob& job = c->fb_job;
+            job.list = c->cur;
+            job.n_entries = n_items;
+            job.view_serial = c->view_serial.load(std::memory_order_relaxed);
+            job.continuous = (fp.flags & (F_LINEAR | F_GAUSSIAN)) != 0u;
+            job.max_grid = max_grid(c);
+            job.waves = PQ_WAVES;
+            job.dp_min_cost = c->dp_min_cost;
+            job.dp_share_pct = c->dp_share_pct;
+            job.fill_cost = c->fill_cost;
+            job.super_fill = c->super_fill;
+            job.only_quarters = c->dev_only_quarters;
+            job.dilate = c->cost_dilate;
+            job.t_us[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            for (int i = 0; i < 3; ++i) job.prio_tenths[i] = c->prio_tenths[i];
+            {
+                std::lock_guard<std::mutex> lk(c->fb_mu);
+                c->fb_state.store(volym_ctx::FB_CAPTURED, std::memory_order_release);
+            }
+            c->fb_cv.notify_all();
+        }
         return VOLYM_OK;
     }
 #define VOLYM_DIRECT_LAUNCH(V, B)                                                                                                \
@@ -841,6 +992,8 @@ static int launch_march(volym_ctx* c)
     return VOLYM_OK;
 }
 
+int volym::ctx_launch_march(volym_ctx* c) { return launch_march<false>(c); }
+
 extern "C" {
 
 int volym_compute_pass(volym_ctx* c)
@@ -849,6 +1002,25 @@ int volym_compute_pass(volym_ctx* c)
     if (!c->have_frame) return fail(c, VOLYM_E_STATE, "volym_compute_pass: call volym_update first");
     HIPCHK(c, hipSetDevice(c->device));
     return launch_march<false>(c);
+}
+
+// Back-pressure of a frame loop: the reference's loop cannot run ahead of the device by more than its swap chain holds
+// (surface.get_current_texture() blocks, src/event_loop.rs:114).  Call once per frame after volym_compute_pass: marks the
+// work enqueued so far and waits until the mark made `max_in_flight` calls ago has been reached.
+int volym_throttle(volym_ctx* c, uint32_t max_in_flight)
+{
+    if (!c) return VOLYM_E_INVALID;
+    if (max_in_flight == 0 || max_in_flight > volym_ctx::THROTTLE_RING) return fail(c, VOLYM_E_INVALID, "volym_throttle: max_in_flight must be 1..8");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t slot = c->throttle_head % volym_ctx::THROTTLE_RING;
+    if (!c->throttle_ev[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->throttle_ev[slot], hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->throttle_ev[slot], c->stream));
+    c->throttle_head++;
+    if (c->throttle_head > max_in_flight) {
+        const uint32_t old = (c->throttle_head - 1u - max_in_flight) % volym_ctx::THROTTLE_RING;
+        if (c->throttle_ev[old]) HIPCHK(c, hipEventSynchronize(c->throttle_ev[old]));
+    }
+    return VOLYM_OK;
 }
 
 int volym_sync(volym_ctx* c)
@@ -875,6 +1047,41 @@ int volym_read_rgba32f(volym_ctx* c, float* out)
         return fail(c, VOLYM_E_STATE, "volym_read_rgba32f: needs VOLYM_OPT_WRITE_F32 = 1, world == 1 and a rendered frame");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out, c->d_f32, static_cast<size_t>(c->W) * c->H * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VOLYM_OK;
+}
+
+// ---- blit: the step after the path (src/render_pipeline.rs:88-130, shaders/render.wgsl:39-43) -------------------------
+int volym_blit(volym_ctx* c, void* target_rgba8, uint32_t out_w, uint32_t out_h)
+{
+    if (!c) return VOLYM_E_INVALID;
+    if (out_w == 0 || out_h == 0 || out_w > 32768 || out_h > 32768) return fail(c, VOLYM_E_INVALID, "volym_blit: target must be 1..32768 in each dimension");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t* dst = static_cast<uint32_t*>(target_rgba8);
+    if (!dst) {
+        // our own target: sized on first use / on a size change (a set-up step: this is the one blocking path of the call)
+        const size_t need = static_cast<size_t>(out_w) * out_h * 4;
+        if (need > c->blit_bytes) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->d_blit) { HIPCHK(c, hipFree(c->d_blit)); c->d_blit = nullptr; c->blit_bytes = 0; }
+            hipError_t e = hipMalloc(&c->d_blit, need);
+            if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("hipMalloc(blit target): ") + hipGetErrorString(e));
+            c->blit_bytes = need;
+        }
+        dst = c->d_blit;
+        c->blit_w = out_w; c->blit_h = out_h;
+    }
+    hipLaunchKernelGGL(volym_blit_kernel, dim3((out_w + 63u) / 64u, (out_h + 3u) / 4u), dim3(64, 4), 0, c->stream, c->d_frame, c->W, c->H, dst, out_w, out_h);
+    HIPCHK(c, hipGetLastError());
+    return VOLYM_OK;
+}
+
+int volym_read_blit(volym_ctx* c, uint8_t* out)
+{
+    if (!c || !out) return VOLYM_E_INVALID;
+    if (!c->d_blit || c->blit_w == 0) return fail(c, VOLYM_E_STATE, "volym_read_blit: no volym_blit into the context's own target yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_blit, static_cast<size_t>(c->blit_w) * c->blit_h * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VOLYM_OK;
 }
@@ -917,10 +1124,6 @@ int volym_pack_shard(volym_ctx* c, void* packed, size_t capacity_bytes)
     const size_t header = pack_header_bytes(c->shard_tiles);
     if (capacity_bytes < header) return fail(c, VOLYM_E_INVALID, "volym_pack_shard: the buffer does not even hold the header (volym_packed_shard_bytes)");
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->d_pack_counters) {
-        HIPCHK(c, hipMalloc(&c->d_pack_counters, 4 * sizeof(uint32_t)));
-        HIPCHK(c, hipMemsetAsync(c->d_pack_counters, 0, 4 * sizeof(uint32_t), c->stream));
-    }
     if (c->n_local == 0) return VOLYM_OK;
     const uint32_t max_slots = static_cast<uint32_t>(std::min<size_t>((capacity_bytes - header) / 1024u, c->shard_tiles));
     hipLaunchKernelGGL(volym_pack_shard_kernel, dim3(c->n_local), dim3(64), 0, c->stream, c->d_shard, static_cast<uint8_t*>(packed), c->n_local,
@@ -933,7 +1136,6 @@ int volym_pack_shard(volym_ctx* c, void* packed, size_t capacity_bytes)
 int volym_packed_tiles(volym_ctx* c, uint32_t* tiles_used, uint32_t* overflowed)
 {
     if (!c || !tiles_used) return VOLYM_E_INVALID;
-    if (!c->d_pack_counters) return fail(c, VOLYM_E_STATE, "volym_packed_tiles: no volym_pack_shard yet");
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t h[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(h, c->d_pack_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -1004,56 +1206,6 @@ int volym_stats_pass(volym_ctx* c, volym_stats* out)
     return VOLYM_OK;
 }
 
-// Development aid: per-item costs (uint16) of the last measuring launch; out needs 4 * n_local entries.
-int volym_dev_read_costs(volym_ctx* c, uint16_t* out, uint32_t max_items)
-{
-    if (!c || !out || !c->d_cost) return VOLYM_E_INVALID;
-    const uint32_t n = c->n_local * 4u;
-    if (max_items < n) return VOLYM_E_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(out, c->d_cost, n * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return static_cast<int>(n);
-}
-
-// Development aid: the work list as the kernel reads it (after cost feedback); returns the number of items.
-int volym_dev_read_order(volym_ctx* c, uint32_t* out, uint32_t max_items)
-{
-    if (!c || !out || !c->d_order) return VOLYM_E_INVALID;
-    if (max_items < c->n_items) return VOLYM_E_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(out, c->d_order, c->n_items * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return static_cast<int>(c->n_items);
-}
-
-// Development aid (not declared in the public header): one instrumented launch that records, per
-// wave, {start tick, duration ticks (100 MHz), max loop iterations of a lane, max dense samples}.
-// out: 4 * grid_blocks uint4 records; returns the number of records or a negative error.
-int volym_dev_wave_trace(volym_ctx* c, uint32_t* out, uint32_t max_records)
-{
-    if (!c || !out) return VOLYM_E_INVALID;
-    if (!c->have_frame) return fail(c, VOLYM_E_STATE, "volym_dev_wave_trace: call volym_update first");
-    HIPCHK(c, hipSetDevice(c->device));
-    const uint32_t records = (c->n_local + 64u) * 4u * 2u;
-    if (max_records < records) return fail(c, VOLYM_E_INVALID, "volym_dev_wave_trace: buffer too small");
-    HIPCHK(c, hipMalloc(&c->d_trace, static_cast<size_t>(records) * sizeof(uint4)));
-    HIPCHK(c, hipMemsetAsync(c->d_trace, 0, static_cast<size_t>(records) * sizeof(uint4), c->stream));
-    // a lone launch on an idle GPU runs at idle clocks: trace the 31st of 31 back-to-back passes
-    int rc = VOLYM_OK;
-    for (int i = 0; i < 30 && rc == VOLYM_OK; ++i) rc = launch_march<false, false>(c);
-    if (rc == VOLYM_OK) rc = launch_march<false, true>(c);
-    if (rc == VOLYM_OK) {
-        hipError_t e = hipMemcpyAsync(out, c->d_trace, static_cast<size_t>(records) * sizeof(uint4), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(c, VOLYM_E_HIP, hipGetErrorString(e));
-    }
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->d_trace);
-    c->d_trace = nullptr;
-    return rc == VOLYM_OK ? static_cast<int>(records) : rc;
-}
-
 int volym_time_batch(volym_ctx* c, uint32_t n, float* ms_total)
 {
     if (!c || !ms_total || n == 0 || n > 1000000) return VOLYM_E_INVALID;
@@ -1097,5 +1249,73 @@ int volym_time_passes(volym_ctx* c, uint32_t n, float* ms_each)
     for (auto e : ev) if (e) (void)hipEventDestroy(e);
     return rc;
 }
+
+#if VOLYM_DEV_SWITCHES
+// ---- development build only (make DEV=1): not declared in the public headers, not in the product library ------------
+// per-item costs (uint16) as the feedback thread last saw them; out needs 4 * n_local entries
+int volym_dev_read_costs(volym_ctx* c, uint16_t* out, uint32_t max_items)
+{
+    if (!c || !out) return VOLYM_E_INVALID;
+    feedback_quiesce(c);
+    const uint32_t n = c->n_local * 4u;
+    if (max_items < n || c->item_cost.size() < n) return VOLYM_E_INVALID;
+    std::memcpy(out, c->item_cost.data(), n * sizeof(uint16_t));
+    return static_cast<int>(n);
+}
+
+// wall-clock stamps (us) of the last finished feedback job: capture enqueued, worker woke, costs arrived, costs mapped to
+// items, list dealt, list uploaded
+int volym_dev_feedback_timing(volym_ctx* c, double out[6])
+{
+    if (!c || !out) return VOLYM_E_INVALID;
+    feedback_quiesce(c);
+    for (int i = 0; i < 6; ++i) out[i] = c->fb_job.t_us[i];
+    return VOLYM_OK;
+}
+
+// the work list the next launch will read; returns the number of entries
+int volym_dev_read_order(volym_ctx* c, uint32_t* out, uint32_t max_items)
+{
+    if (!c || !out) return VOLYM_E_INVALID;
+    feedback_quiesce(c);
+    const WorkList& wl = c->lists[c->cur];
+    if (max_items < wl.entries.size()) return VOLYM_E_INVALID;
+    std::memcpy(out, wl.entries.data(), wl.entries.size() * sizeof(uint32_t));
+    return static_cast<int>(wl.entries.size());
+}
+
+// One instrumented launch that records, per wave, {start tick, duration ticks (100 MHz), loop iterations, ...} (two
+// uint4 per wave, scripts/wave_trace.py); returns the number of records or a negative error.
+int volym_dev_wave_trace(volym_ctx* c, uint32_t* out, uint32_t max_records)
+{
+    if (!c || !out) return VOLYM_E_INVALID;
+    if (!c->have_frame) return fail(c, VOLYM_E_STATE, "volym_dev_wave_trace: call volym_update first");
+    HIPCHK(c, hipSetDevice(c->device));
+    // a lone launch on an idle GPU runs at idle clocks: trace the 31st of 31 back-to-back passes
+    int rc = VOLYM_OK;
+    for (int i = 0; i < 30 && rc == VOLYM_OK; ++i) rc = launch_march<false, false>(c);
+    if (rc != VOLYM_OK) return rc;
+    feedback_quiesce(c);
+    // records: two per wave of the grid that is really launched (variant 2: the list's grid; variants 0/1: 4 waves per tile)
+    const WorkList& wl = c->lists[c->cur];
+    const uint32_t n_items = static_cast<uint32_t>(wl.entries.size());
+    const uint32_t pgrid = wl.grid ? wl.grid : std::max(1u, std::min((n_items + PQ_WAVES - 1) / PQ_WAVES, max_grid(c)));
+    const uint32_t waves = c->kernel_variant == 2 ? pgrid * PQ_WAVES : (c->n_local + 64u * 8u) * 4u;
+    const uint32_t records = waves * 2u;
+    if (max_records < records) return fail(c, VOLYM_E_INVALID, "volym_dev_wave_trace: buffer too small");
+    HIPCHK(c, hipMalloc(&c->d_trace, static_cast<size_t>(records) * sizeof(uint4)));
+    HIPCHK(c, hipMemsetAsync(c->d_trace, 0, static_cast<size_t>(records) * sizeof(uint4), c->stream));
+    rc = launch_march<false, true>(c);
+    if (rc == VOLYM_OK) {
+        hipError_t e = hipMemcpyAsync(out, c->d_trace, static_cast<size_t>(records) * sizeof(uint4), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, VOLYM_E_HIP, hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_trace);
+    c->d_trace = nullptr;
+    return rc == VOLYM_OK ? static_cast<int>(records) : rc;
+}
+#endif
 
 }  // extern "C"

@@ -206,8 +206,12 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         // item = local_tile*4 + sub (an 8x8 wave tile, one lane per ray), or, for tiles the cost feedback
         // found expensive, bit 31 | (that id << 2) | quarter: a 4x4 quarter tile marched DEPTH-PARALLEL,
         // four lanes per ray, lane k of a quad taking the k-th speculative sample (see "dp" below)
-        const uint32_t raw_p = __builtin_amdgcn_readfirstlane(ticket < PQ_ITEMS_LDS ? s_items[ticket] : order[blockIdx.x + static_cast<size_t>(gridDim.x) * ticket]);
+        const size_t list_pos = blockIdx.x + static_cast<size_t>(gridDim.x) * ticket;     // this entry's place in the work list
+        const uint32_t raw_p = __builtin_amdgcn_readfirstlane(ticket < PQ_ITEMS_LDS ? s_items[ticket] : order[list_pos]);
         if (raw_p == PQ_NO_ITEM) continue;
+        // counted cost of this list entry, reported by list position (one writer per entry: no atomics, nothing to reset); the
+        // host's feedback thread maps positions back to tiles (raymarch.hip, "cost feedback")
+        uint32_t entry_cost = 0;
         // bits 28-29: issue priority the host derived from the measured cost.  The frame ends with its longest chains of
         // dependent samples; a wave that carries one gets the SIMD's issue slots first, the cheap items fill the gaps.
         switch ((raw_p >> 28) & 3u) {
@@ -249,6 +253,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                         out_shard[static_cast<size_t>(lt) * 256u + sl] = (gxx < fp.W && gyy < fp.H) ? packed : 0u;
                     }
                 }
+                if (cost && lane == 0) cost[list_pos] = 0;
                 continue;
             }
             n_sub = 4;
@@ -287,8 +292,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 } else {
                     out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + sub_lane] = in_frame ? packed : 0u;
                 }
-                if (cost && lane == 0) cost[item] = 0;
-                continue;
+                continue;                                    // a constant tile costs (next to) nothing
             }
         }
         if (TRACE) trace_marched++;
@@ -493,6 +497,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
                 bool try_leap = true;
                 active = active && t < t_end;
                 while (__ballot(active) != 0ull) {
+                    tile_iters++;
                     if (TRACE) { trace_iters++; trace_dp_iters++; trace_lanes += static_cast<uint32_t>(__popcll(__ballot(active))); tm_mark = PQ_TICK(); }
                     // a leap is worth looking for only where the march just ran through a whole batch of non-dense samples
                     // (or has not sampled yet); `active` is up to date either way
@@ -607,6 +612,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             } else {
             const bool use_alpha_dp = imp_coloring || (flags & F_OPACITY) != 0u;
             while (__ballot(active) != 0ull) {
+                tile_iters++;
                 if (TRACE) { trace_iters++; trace_dp_iters++; trace_lanes += static_cast<uint32_t>(__popcll(__ballot(active))); tm_mark = PQ_TICK(); }
                 leap_phase();
                 if (TRACE) { const unsigned long long now = PQ_TICK(); tm_leap += now - tm_mark; tm_mark = now; }
@@ -935,10 +941,13 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
         }
         // cost of the tile as the scheduler sees it, in units of ~56 instructions: ray set-up, loop iterations, shading
         // batches, replayed steps (counted, not timed: the work list must not depend on the weather)
-        if (cost && !dp && lane == 0) cost[item] = static_cast<uint16_t>(min(65535u, 5u + tile_iters * 5u + tile_flushes * 2u + tile_trips / 7u));
+        // a depth-parallel iteration takes 8 samples per ray where the classic loop takes 4: its iterations count double, so
+        // that a quarter's number estimates what its tile would cost as one item (the host takes the maximum of the four)
+        entry_cost += dp ? tile_iters * 10u + tile_flushes * 2u + tile_trips / 7u : 5u + tile_iters * 5u + tile_flushes * 2u + tile_trips / 7u;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
+      if (cost && lane == 0) cost[list_pos] = static_cast<uint16_t>(min(65535u, entry_cost));
       }
     }
 

@@ -93,6 +93,25 @@ class GpuContext:
     def sync(self):
         self._ck(_lib.lib().volym_sync(self.handle))
 
+    def throttle(self, max_in_flight=3):
+        """Frame-loop back-pressure (the swap chain's role, src/event_loop.rs:114): at most `max_in_flight` frames ahead."""
+        self._ck(_lib.lib().volym_throttle(self.handle, int(max_in_flight)))
+
+    def settle(self):
+        """Wait until a re-deal of the work lists in flight (cost feedback) has been adopted."""
+        self._ck(_lib.lib().volym_settle(self.handle))
+
+    def blit(self, out_w, out_h, target_ptr=None):
+        """RenderPipeline::render_pass (src/render_pipeline.rs:88-130): frame -> out_w x out_h target."""
+        self._blit_size = (int(out_h), int(out_w))
+        self._ck(_lib.lib().volym_blit(self.handle, C.c_void_p(target_ptr), int(out_w), int(out_h)))
+
+    def read_blit(self):
+        h, w = self._blit_size
+        out = np.empty((h, w, 4), np.uint8)
+        self._ck(_lib.lib().volym_read_blit(self.handle, scene._u8p(out)))
+        return out
+
     # ---- output -----------------------------------------------------------------------------
     def read_rgba8(self):
         out = np.empty((self.height, self.width, 4), np.uint8)
