@@ -9,11 +9,14 @@ A "step" is one frame: one pass of the ray-march over every pixel of the viewpor
 with step 0.01, the reference's effective camera eye (0.5,0.5,1.5)).  The real .raw is not in
 the repository (.MISSING_LARGE_BLOBS), so the volume is volym_amd.synth.synth_bonsai(256).
 
-N > 1: the framebuffer is sharded by interleaved 16x16 screen tiles over the ranks, the volume
-is replicated, and every frame's shards are gathered to rank 0 over RCCL (rooted gather: direct
-sends over separate xGMI links) and assembled into a raster there; a frame's gather overlaps the
-marches of the next three frames (four buffers).
-Total work per step is fixed, so scaling is "strong".
+N > 1 (one process per GPU, launched by torch.distributed.run): the framebuffer is sharded by interleaved
+16x16 screen tiles over the ranks, the volume is replicated, and every frame's PACKED shards (only the tiles
+that are not constant) are sent straight to rank 0 over RCCL (grouped ncclSend / ncclRecv: the root's inbound
+traffic uses all its xGMI links) and assembled into the raster there.  The frame loop is native
+(include/volym_mgpu.h): one C call runs the K frames -- rotating buffers, a compute and a communication stream
+per device, a captured HIP graph for the static view -- and torch.distributed (gloo) is only the control plane
+(the RCCL id, the barriers, the maximum over the ranks of the time).  Total work per step is fixed: "strong".
+--virtual-ranks N rehearses the same loop on ONE GPU (N contexts, device copies instead of RCCL).
 """
 import argparse
 import json
@@ -96,6 +99,20 @@ def frame_check(args, dims, volume, importances, lut, state, got_u8, n_rows=68):
     return "MISMATCH: %d of %d sampled pixels differ from the oracle by more than 1 LSB (max %d)" % (int((d.max(axis=-1) > 1).sum()), len(rows) * W, int(d.max()))
 
 
+def make_context(args, demo, _lib, W, H, device, dims, volume, importances, lut, state):
+    ctx = demo.GpuContext(W, H, device)
+    ctx.set_option(_lib.OPT_KERNEL, args.kernel)
+    if args.layout >= 0:
+        ctx.set_option(_lib.OPT_VOLUME_LAYOUT, args.layout)
+    if args.xcd_bands >= 0:
+        ctx.set_option(_lib.OPT_XCD_BANDS, args.xcd_bands)
+    ctx.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
+    ctx.set_importances(importances, dims)
+    ctx.set_transfer_function(lut)
+    ctx.update(state.camera_uniforms(), state.parameter_uniforms())
+    return ctx
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,10 +125,8 @@ def main():
     ap.add_argument("--layout", type=int, default=-1, help="volume layout: -1 by size (bricks beyond 64 MiB), 0 linear, 1 4x4x4 bricks")
     ap.add_argument("--kernel", type=int, default=2,
                     help="0 direct (BASELINE configs[1]), 1 macro-cell, 2 persistent workgroups + LDS-staged tables/distance field + shading queue (configs[2], default)")
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the driver's runs) or gloo (rehearsal on one device)")
-    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
-    ap.add_argument("--frames-per-gather", type=int, default=4, help="N > 1, packed shards: frames batched into one collective")
-    ap.add_argument("--full-gather", action="store_true", help="N > 1: gather whole shards instead of packed ones (only the tiles that are not constant)")
+    ap.add_argument("--virtual-ranks", type=int, default=0, help="rehearsal on one GPU: N contexts on device 0 through the native multi-GPU loop, device copies instead of RCCL")
+    ap.add_argument("--no-graph", action="store_true", help="N > 1: plain enqueues instead of replaying a captured HIP graph")
     ap.add_argument("--linear", action="store_true", help="trilinear volume filter (north_star mode)")
     ap.add_argument("--importance", action="store_true")
     ap.add_argument("--gaussian", action="store_true", help="use_gaussian_smoothing = 1 (the interactive default, src/state.rs:50)")
@@ -121,7 +136,7 @@ def main():
     ap.add_argument("--no-moving-view", action="store_true", help="skip the first-frame and turntable timings (N = 1)")
     ap.add_argument("--turntable-frames", type=int, default=720)
     ap.add_argument("--turntable-degrees", type=float, default=0.25, help="rotation between consecutive views of the turntable")
-    ap.add_argument("--no-frame-check", action="store_true", help="skip the untimed N = 1 check of the steady-state frame against the oracle")
+    ap.add_argument("--no-frame-check", action="store_true", help="skip the untimed check of the frame against the oracle")
     ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs[0..4] presets (default = c3, the configuration the metric is quoted on): "
                          "c1 teapot 512x512, c2 bonsai 1080p direct kernel, c3 bonsai 1080p, c4 bonsai 4K, c5 synthetic 1024^3 + labels 4K importance")
@@ -139,201 +154,108 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from volym_amd import _lib, demo
+    from volym_amd import _lib, demo, mgpu
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    procs = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
+    if procs != args.gpus:
+        if procs == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = procs
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    if args.same_device:
-        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    world = args.virtual_ranks if (procs == 1 and args.virtual_ranks > 1) else procs    # ranks the frame is sharded over
+    if procs > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
+        dist.init_process_group("gloo")          # control plane only; the data path is RCCL inside libvolym_hip.so
 
     dims, volume, importances, lut, state = build_scene(args)
     W, H = args.width, args.height
+    exit_code = 0
+    gather_check = frame_check_result = None
+    first_frame_ms = moving_view_ms = static_views_ms = None
+    mg_info = None
 
-    ctx = demo.GpuContext(W, H, local_rank)
-    ctx.set_option(_lib.OPT_KERNEL, args.kernel)
-    if args.layout >= 0:
-        ctx.set_option(_lib.OPT_VOLUME_LAYOUT, args.layout)
-    if args.xcd_bands >= 0:
-        ctx.set_option(_lib.OPT_XCD_BANDS, args.xcd_bands)
-    ctx.set_shard(rank, world)
-    ctx.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
-    ctx.set_importances(importances, dims)
-    ctx.set_transfer_function(lut)
-    # an explicit (non-null) stream shared by the march kernels, the assemble kernel and torch: RCCL's stream
-    # orders itself against THIS stream (the null stream would mean "the context's own stream" to the C ABI)
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    ctx.set_stream(stream.cuda_stream)
-    ctx.update(state.camera_uniforms(), state.parameter_uniforms())
-
-    shard_bytes = ctx.shard_bytes()
-    nbuf = 4       # frames in flight: frame i's gather overlaps the marches of frames i+1..i+3
-    frame = torch.empty(W * H * 4, dtype=torch.uint8, device=dev)
-    packed_mode = world > 1 and not args.full_gather
-    msg_bytes, packed_tiles = shard_bytes, None
-    if world > 1:
-        shards = [torch.empty(shard_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-        if packed_mode:
-            # Most 16x16 tiles of a frame are constant (outside the silhouette): the gather moves a header plus the tiles
-            # that are not (volym_pack_shard).  One untimed frame sizes the messages: the maximum over the ranks of the
-            # number of stored tiles (the view is static; a tile that found no room would raise the overflow flag).
-            cap = ctx.packed_shard_bytes(1 << 30)
-            probe = torch.empty(cap, dtype=torch.uint8, device=dev)
-            ctx.bind_output(shards[0].data_ptr(), frame.data_ptr())
+    if world == 1:
+        # ---------------------------------------------- one GPU -----------------------------------------------------
+        ctx = make_context(args, demo, _lib, W, H, local_rank, dims, volume, importances, lut, state)
+        frame = torch.empty(W * H * 4, dtype=torch.uint8, device=dev)
+        ctx.bind_output(None, frame.data_ptr())
+        for _ in range(args.warmup):
             ctx.compute_pass()
-            ctx.pack_shard(probe.data_ptr(), cap)
-            used, _ = ctx.packed_tiles()
-            t = torch.tensor([used], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            packed_tiles = int(t.item())
-            msg_bytes = ctx.packed_shard_bytes(packed_tiles)
-            del probe
-        # frames per collective: launching a collective from Python costs more than a rank's march of a 1/8 frame, so the
-        # packed shards of F consecutive frames travel together (frame f of a batch sits at offset f * msg_bytes)
-        F = max(1, args.frames_per_gather) if packed_mode else 1
-        if packed_mode:
-            packed = [torch.empty(F * msg_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-        # only the root consumes the frame: a rooted gather = direct sends to rank 0 over separate xGMI links
-        # (a ring all_gather would move 7x the bytes through every link)
-        gathered = [torch.empty(F * msg_bytes * world, dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(nbuf)]
-        gather_lists = [list(g.view(world, F * msg_bytes).unbind(0)) if g is not None else None for g in gathered]
-    ctx.bind_output(shards[0].data_ptr() if world > 1 else None, frame.data_ptr())
-
-    pending = [None] * nbuf
-    filled = [0] * nbuf          # packed mode: frames of the batch in buffer b that have been rendered
-    issued = {"frames": 0}       # frames issued so far (the batch and slot of the next one follow from it)
-
-    def assemble(b):
-        if packed_mode:
-            for f in range(filled[b]):
-                ctx.assemble_packed(gathered[b].data_ptr() + f * msg_bytes, F * msg_bytes)
-        else:
-            ctx.assemble(gathered[b].data_ptr())
-
-    def retire(b):
-        if pending[b] is not None:          # buffer b's previous gather + assemble must be done before it is reused
-            pending[b].wait()
-            if rank == 0:
-                assemble(b)
-            pending[b] = None
-            filled[b] = 0
-
-    def one_frame(_i):
-        if world == 1:
-            ctx.compute_pass()
-            return
-        i = issued["frames"]
-        issued["frames"] = i + 1
-        if packed_mode:
-            b, f = (i // F) % nbuf, i % F
-            if f == 0:
-                retire(b)
-            ctx.compute_pass()              # into shards[0]: the pack below reads it before the next march starts (same stream)
-            ctx.pack_shard(packed[b].data_ptr() + f * msg_bytes, msg_bytes)
-            filled[b] = f + 1
-            if f == F - 1:
-                pending[b] = dist.gather(packed[b], gather_lists[b], dst=0, async_op=True)
-        else:
-            b = i % nbuf
-            retire(b)
-            ctx.bind_output(shards[b].data_ptr(), frame.data_ptr())
-            ctx.compute_pass()
-            pending[b] = dist.gather(shards[b], gather_lists[b], dst=0, async_op=True)
-
-    def drain():
-        if world == 1:
-            return
-        if packed_mode:                     # a batch that is not full yet still has to travel
-            i = issued["frames"]
-            if i % F != 0:
-                b = (i // F) % nbuf
-                pending[b] = dist.gather(packed[b], gather_lists[b], dst=0, async_op=True)
-                issued["frames"] = (i // F + 1) * F
-        for b in range(nbuf):
-            retire(b)
-
-    for i in range(args.warmup):
-        one_frame(i)
-    drain()
-    torch.cuda.synchronize(dev)
-    ctx.settle()        # the work lists dealt from the warm-up frames' costs are in place before the timed region
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_frame(i)
-    drain()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    # ---- untimed self-check of the N > 1 path: the gathered + assembled frame must equal the frame one context
-    # renders alone (same pixels whatever the sharding) -------------------------------------
-    gather_check = None
-    if world > 1:
-        one_frame(0)
-        drain()
+        ctx.sync()
+        ctx.settle()        # the work lists dealt from the warm-up frames' costs are in place before the timed region
         torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.compute_pass()
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        local = ctx
+    else:
+        # ---------------------------------------------- N GPUs (or N virtual ranks) ---------------------------------
+        if procs > 1:
+            obj = [mgpu.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(obj, src=0)
+            mg = mgpu.MultiGpu(W, H, rank=rank, world=world, device_id=local_rank, uid=obj[0])
+        else:
+            mg = mgpu.MultiGpu(W, H, devices=[local_rank] * world, transport=mgpu.COPY)
+        mg.set_option(_lib.OPT_KERNEL, args.kernel)
+        if args.layout >= 0:
+            mg.set_option(_lib.OPT_VOLUME_LAYOUT, args.layout)
+        mg.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
+        mg.set_importances(importances, dims)
+        mg.set_transfer_function(lut)
+        mg.update(state.camera_uniforms(), state.parameter_uniforms())
+        mg.prepare(0)                       # sizes the packed messages: one untimed frame, maximum over the ranks
+        use_graph = not args.no_graph
+        mg.run(max(args.warmup, 1), use_graph)
+        torch.cuda.synchronize(dev)
+        if procs > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        tim = mg.run(args.steps, use_graph)
+        torch.cuda.synchronize(dev)
+        if procs > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        over = tim["overflowed"]
+        if procs > 1:
+            t = torch.tensor([dt, float(over)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, over = float(t[0]), int(t[1])
+        split = mg.profile(8)
+        mg_info = {"loop": "native (volym_mgpu_run): %s" % ("HIP graph, %d replays of a 4-frame cycle" % tim["graph_replays"] if tim["graph_replays"] else "plain enqueues"),
+                   "transport": "RCCL grouped ncclSend/ncclRecv to rank 0" if procs > 1 else "device copies (virtual ranks on one GPU)",
+                   "packed_bytes_per_rank_and_frame": tim["msg_bytes"], "whole_shard_bytes": mgpu_shard_bytes(W, H, world),
+                   "host_enqueue_us_per_frame": tim["enqueue_us_per_frame"], "per_stage_ms_rank0": split}
+        # untimed self-check: the gathered + assembled frame must equal the frame one context renders alone
         if rank == 0:
-            assembled = frame.clone()
-            solo = demo.GpuContext(W, H, local_rank)
-            solo.set_option(_lib.OPT_KERNEL, args.kernel)
-            if args.layout >= 0:
-                solo.set_option(_lib.OPT_VOLUME_LAYOUT, args.layout)
-            solo.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
-            solo.set_importances(importances, dims)
-            solo.set_transfer_function(lut)
-            solo.update(state.camera_uniforms(), state.parameter_uniforms())
+            assembled = mg.read_rgba8()
+            solo = make_context(args, demo, _lib, W, H, local_rank, dims, volume, importances, lut, state)
             solo.compute_pass()
             solo.sync()
-            ref = torch.from_numpy(solo.read_rgba8().reshape(-1))
+            ref = solo.read_rgba8()
             solo.close()
-            gather_check = "ok" if bool(torch.equal(assembled.cpu(), ref)) else "MISMATCH"
-        if packed_mode:                      # no rank may have run out of room in its packed shard
-            over = torch.tensor([ctx.packed_tiles()[1]], dtype=torch.int64, device=dev)
-            dist.all_reduce(over, op=dist.ReduceOp.MAX)
-            if rank == 0 and int(over.item()) != 0:
-                gather_check = "OVERFLOW"
-        dist.barrier()
+            gather_check = "ok" if np.array_equal(assembled, ref) else "MISMATCH: the assembled frame differs from the frame one context renders alone in %d bytes" % int((assembled != ref).sum())
+            if over:
+                gather_check = "OVERFLOW: a packed shard ran out of room"
+            if gather_check == "ok" and not args.no_frame_check:
+                frame_check_result = frame_check(args, dims, volume, importances, lut, state, assembled)
+        local = demo.GpuContext.borrow(mg.context_handle(0), W, H)
 
     # ---- untimed self-check of the N = 1 path: the frame the timed loop left behind (a steady-state frame: cost-ordered
     # work lists, super-fill stores, no float buffer) against a fresh context's first frame (bit-equal) and against the
     # oracle on sampled rows (<= 1 LSB) -------------------------------------------------------------------------------
-    frame_check_result = None
     if world == 1 and not args.no_frame_check:
-        torch.cuda.synchronize(dev)
         got = frame.cpu().numpy().reshape(H, W, 4)
-        solo = demo.GpuContext(W, H, local_rank)
-        solo.set_option(_lib.OPT_KERNEL, args.kernel)
-        if args.layout >= 0:
-            solo.set_option(_lib.OPT_VOLUME_LAYOUT, args.layout)
-        solo.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
-        solo.set_importances(importances, dims)
-        solo.set_transfer_function(lut)
-        solo.update(state.camera_uniforms(), state.parameter_uniforms())
+        solo = make_context(args, demo, _lib, W, H, local_rank, dims, volume, importances, lut, state)
         solo.compute_pass()
         solo.sync()
         first = solo.read_rgba8()
@@ -346,7 +268,6 @@ def main():
     # ---- beside the steady state (N = 1): the first frame of a view nobody has measured (centre-first list, what a
     # context without cost feedback runs every frame) and a moving view: a turntable of the orbit camera, every frame a new
     # pose (src/camera.rs:47-61, src/event_loop.rs:100-119), the lists following it through the asynchronous feedback ------
-    first_frame_ms = moving_view_ms = static_views_ms = None
     if world == 1 and args.kernel == 2 and not args.no_moving_view:
         from volym_amd import scene
         ctx.set_option(_lib.OPT_COST_FEEDBACK, 0)
@@ -376,14 +297,14 @@ def main():
             ctx.update(cu, pu)
             ctx.compute_pass()
             ctx.throttle(3)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
+        ctx.sync()
+        t1 = time.perf_counter()
         for cu, pu in views[60:]:
             ctx.update(cu, pu)
             ctx.compute_pass()
             ctx.throttle(3)
-        torch.cuda.synchronize(dev)
-        moving_view_ms = (time.perf_counter() - t0) / n_tt * 1e3
+        ctx.sync()
+        moving_view_ms = (time.perf_counter() - t1) / n_tt * 1e3
         ctx.update(state.camera_uniforms(), state.parameter_uniforms())   # back to the bench view for what follows
         ctx.time_batch(3)
         ctx.settle()
@@ -391,24 +312,33 @@ def main():
     # ---- roofline of the dominant kernel: HIP events on the kernel's stream, algorithmic bytes from the
     # instrumented launch (reference fetch counts) -------------------------------------------------------
     n_ev = min(max(args.steps, 10), 500)
-    kernel_ms = ctx.time_batch(n_ev) / n_ev      # HIP events on the kernel's stream, one pair around n_ev launches
-    ctx.sync()
-    st = ctx.stats_pass()
-    counts = torch.tensor([st["n_vol"], st["n_imp"], st["n_rays"]], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(counts)
-    n_vol, n_imp, n_rays = (int(x) for x in counts.tolist())
+    local.time_batch(3)
+    local.settle()
+    kernel_ms = local.time_batch(n_ev) / n_ev      # HIP events on the kernel's stream, one pair around n_ev launches
+    local.sync()
+    st = local.stats_pass()
+    counts = [st["n_vol"], st["n_imp"], st["n_rays"]]
+    if procs > 1:
+        t = torch.tensor(counts, dtype=torch.int64)
+        dist.all_reduce(t)
+        counts = [int(x) for x in t.tolist()]
+    elif world > 1:                                  # virtual ranks: add the other contexts' counts
+        for i in range(1, world):
+            s_i = mg.stats_pass(i)
+            counts = [counts[0] + s_i["n_vol"], counts[1] + s_i["n_imp"], counts[2] + s_i["n_rays"]]
+    n_vol, n_imp, n_rays = counts
     b_vol = 8 if args.linear else 1
     local_bytes = st["n_vol"] * b_vol + st["n_imp"] + 4 * st["n_rays"]      # this rank's launch
     frame_bytes = n_vol * b_vol + n_imp + 4 * W * H                           # whole frame (B_alg)
     achieved = local_bytes / (kernel_ms * 1e-3) / 1e9
 
-    # the instantiation launch_march picks for this workload (raymarch.hip): <TABLE, COUNT, TRACE, K, IMP, BRICK, IR>
+    # the instantiation launch_march picks for this workload (raymarch.hip): <TABLE, COUNT, TRACE, K, IMP, BRICK, IR, WAVES>
     continuous = bool(args.linear or args.gaussian)
     bricked = args.layout == 1 or (args.layout < 0 and dims[0] * dims[1] * dims[2] > (64 << 20))
-    pq_kernel_name = "volym_raymarch_pq_kernel<%s,false,false,%d,%s,%s,%s>" % (
+    ir = bool(args.importance and not continuous)
+    pq_kernel_name = "volym_raymarch_pq_kernel<%s,false,false,%d,%s,%s,%s,%d>" % (
         "false" if continuous else "true", 1 if continuous else 4, "true" if continuous else "false",
-        "true" if bricked else "false", "true" if (args.importance and not continuous) else "false")
+        "true" if bricked else "false", "true" if ir else "false", 12 if (ir and bricked) else 16)
     # HBM-side traffic of one launch: PMC counters cannot be read from inside this process; use the committed
     # rocprofv3 measurement of this exact workload when there is one (profiles/rNN_traffic.json)
     traffic, traffic_src = None, None
@@ -421,14 +351,13 @@ def main():
                 break
             except Exception:
                 pass
-    exit_code = 0
     if rank == 0:
         rays = W * H
         out = {
             "metric": "Mrays/s + achieved HBM GB/s, 256^3 uint8 @ 1920x1080",
             "value": rays * args.steps / dt / 1e6,
             "unit": "Mrays/s",
-            "n_gpus": world,
+            "n_gpus": procs if procs > 1 else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -443,7 +372,8 @@ def main():
                                (", importance look-ahead %s" % ("cone" if args.cone else "straight") if args.importance else "") + (", gaussian smoothing" if args.gaussian else ""),
                                {0: "direct", 1: "macro-cell", 2: "persistent workgroups, TF tables + distance field in LDS, shading queue, wave-ballot exit"}[args.kernel], 1 if args.kernel == 0 else 2),
                 "viewport": [W, H], "volume": list(dims), "tile_sharding": "interleaved 16x16 tiles, k %% %d" % world,
-                "gather": (None if world == 1 else ("packed shards: %d bytes per rank and frame (header + %d tiles that are not constant; a whole shard is %d bytes)" % (msg_bytes, packed_tiles, shard_bytes)) if packed_mode else ("whole shards: %d bytes per rank and frame" % shard_bytes)),
+                "virtual_ranks": (world if (procs == 1 and world > 1) else None),
+                "gather": mg_info,
             },
             "gather_check": gather_check,
             "frame_check": frame_check_result,
@@ -459,8 +389,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": pq_kernel_name if args.kernel == 2 else "volym_raymarch_kernel<%d,false,false>" % args.kernel,
                 "kernel_avg_ms": kernel_ms, "launch_algorithmic_bytes": local_bytes,
-                "note": "algorithmic bytes = reference fetch count (n_vol*%d + n_imp) + 4 B/pixel; the 32 MiB working set is "
-                        "Infinity-Cache resident, so HBM traffic << algorithmic bytes (DESIGN.md)" % b_vol,
+                "note": "algorithmic bytes = reference fetch count (n_vol*%d + n_imp) + 4 B/pixel of %s; the 32 MiB working set is "
+                        "Infinity-Cache resident, so HBM traffic << algorithmic bytes (DESIGN.md)" % (b_vol, "this rank's launch" if world > 1 else "the launch"),
             },
         }
         if not args.no_cpu_baseline and world == 1:
@@ -475,13 +405,21 @@ def main():
             out["error"] = "; ".join(failed)
         print(json.dumps(out))
         exit_code = 1 if failed else 0
-    ctx.close()
-    if world > 1:
-        code = torch.tensor([exit_code], dtype=torch.int64, device=dev)
+    if world == 1:
+        ctx.close()
+    else:
+        mg.close()
+    if procs > 1:
+        code = torch.tensor([exit_code], dtype=torch.int64)
         dist.broadcast(code, src=0)
         exit_code = int(code.item())
         dist.destroy_process_group()
     sys.exit(exit_code)
+
+
+def mgpu_shard_bytes(W, H, world):
+    from volym_amd import sharding
+    return sharding.shard_bytes(W, H, world)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Ablation timings of the march kernel (development aid, not part of the bench contract)."""
+"""Ablation timings of the march kernel (development aid, not part of the bench contract).
+Needs the DEV build: make -C volym_amd/csrc DEV=1; VOLYM_HIP_LIB=volym_amd/libvolym_hip_dev.so python scripts/ablate.py ..."""
 import argparse
 import ctypes as C
 import os
@@ -63,18 +64,18 @@ def main():
                 for b, ks, cl, fb in [(b, ks, cl, fb) for b in (args.bands if k != 2 else args.wgs) for ks in (args.kspec if k == 2 else [1]) for cl in (args.cull if k == 2 else [1]) for fb in (args.feedback if k == 2 else [0])]:
                   for dpc, fine in [(d, f) for d in (args.dp if k == 2 else [0]) for f in (args.prio if k == 2 else [0])]:
                    for dev in args.dev:
-                    ctx.set_option(105, dpc)
+                    ctx.set_option(_lib.OPT_DEPTH_PARALLEL, dpc)
                     ctx.set_option(108, fine)
                     ctx.set_option(109, args.only_quarters)
                     ctx.set_option(111, args.balance)
-                    ctx.set_option(102, ks)
-                    ctx.set_option(103, cl)
-                    ctx.set_option(104, fb)
+                    ctx.set_option(_lib.OPT_CULLING, cl)
+                    ctx.set_option(_lib.OPT_COST_FEEDBACK, fb)
                     ctx.set_option(_lib.OPT_KERNEL, k)
                     ctx.set_option(_lib.OPT_XCD_BANDS if k != 2 else 101, b)
                     ctx.update(cu, pu)
                     ctx.set_option(110, dev)
                     ctx.time_passes(5)
+                    ctx.settle()
                     ms = ctx.time_passes(args.n)
                     batch = 1e3 * ctx.time_batch(args.n) / args.n
                     st = ctx.stats_pass()

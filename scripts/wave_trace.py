@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-wave timeline of one instrumented march launch (development aid)."""
+"""Per-wave timeline of one instrumented march launch (development aid).
+Needs the DEV build: make -C volym_amd/csrc DEV=1; VOLYM_HIP_LIB=volym_amd/libvolym_hip_dev.so python scripts/wave_trace.py --kernel 2"""
 import argparse
 import ctypes as C
 import os
@@ -37,9 +38,10 @@ def main():
         ctx.set_transfer_function(scene.default_lut())
         ctx.set_option(_lib.OPT_KERNEL, args.kernel)
         ctx.set_option(_lib.OPT_XCD_BANDS if args.kernel != 2 else 101, args.bands if args.kernel != 2 else max(args.bands, 1))
+        ctx.set_option(114, 0)
         ctx.update(state.camera_uniforms(), state.parameter_uniforms())
         ctx.stats_pass()
-        nrec = (ctx.local_tiles() + 64) * 8
+        nrec = (ctx.local_tiles() + 1024) * 8
         buf = np.zeros((nrec, 4), np.uint32)
         import time
         for rep in range(3):

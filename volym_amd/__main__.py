@@ -70,6 +70,7 @@ def benchmark(args):
             state.update()                                          # src/event_loop.rs:100
             d.update_gpu_state(ctx, state)
             ms = ctx.time_passes(8)                                 # warm-up; also sizes the trial
+            ctx.settle()                                            # the work list dealt from the warm-up frames is in place
             per = max(float(np.median(ms)), 1e-3)
             n = int(min(max(args.secs * 1e3 / per, 4), 20000))
             frames, times, ftimes, fps = [], [], [], []
@@ -114,11 +115,50 @@ def run_simple(args):
     return 0
 
 
+def flythrough(args):
+    """Scripted fly-through (volym_amd/flythrough.py): mouse orbit, scroll zoom and every
+    widget of the reference's panel over its range (src/gui.rs:198-277), one event + update + compute pass per frame
+    (src/event_loop.rs:100-119).  --out DIR keeps every --keep-every-th frame as PNG and writes frames.json: the uniforms
+    each kept frame was rendered with (what a test needs to render the same frames with the oracle)."""
+    import json
+    import os
+    from . import flythrough as ft
+    W, H = args.width, args.height
+    raw, labels, segments, what = _load_assets(args)
+    state = scene.State.with_parameters(W / H, scene.StateParameters())      # the interactive defaults, src/state.rs:41-55
+    state.update()
+    kept, times = [], []
+    with demo.GpuContext(W, H, args.device) as ctx:
+        d = demo.Simple.init(ctx, state, volume_raw=raw, labels_raw=labels, segments=segments, dims=(256, 256, 256))
+        for i, ev in enumerate(ft.script(args.frames)):
+            ft.apply(state, ev)
+            state.update()
+            d.update_gpu_state(ctx, state)
+            t0 = time.perf_counter()
+            d.compute_pass(ctx)
+            ctx.throttle(3)
+            times.append(time.perf_counter() - t0)
+            if args.out and i % max(1, args.keep_every) == 0:
+                ctx.sync()
+                name = "fly_%04d.png" % i
+                image.write_png(os.path.join(args.out, name), ctx.read_rgba8())
+                kept.append({"frame": i, "event": list(ev), "png": name,
+                             "camera_uniforms": bytes(state.camera_uniforms()).hex(),
+                             "parameter_uniforms": bytes(state.parameter_uniforms()).hex()})
+        ctx.sync()
+    if args.out:
+        with open(os.path.join(args.out, "frames.json"), "w") as f:
+            json.dump({"width": W, "height": H, "frames": kept}, f)
+    t = np.array(times)
+    print("flythrough: %s, %dx%d, %d frames, %d kept: mean %.3f ms per frame (enqueue + back-pressure, 3 frames in flight)" % (
+        what, W, H, args.frames, len(kept), t.mean() * 1e3))
+    return 0
+
+
 def turntable(args):
-    """Scripted fly-through: the camera orbits the volume the way a mouse drag does
-    (State.process_mouse -> CameraController -> Camera::orbit, src/camera.rs:47-61, :96-117), one update +
-    compute pass per frame.  Every frame has a new view, so the kernel's cost feedback never engages: this is
-    the moving-camera figure."""
+    """The camera orbits the volume the way a mouse drag does (State.process_mouse -> CameraController -> Camera::orbit,
+    src/camera.rs:47-61, :96-117), one update + compute pass per frame, every frame a new view: the moving-camera
+    figure (the work lists follow the view through the asynchronous cost feedback)."""
     W, H = args.width, args.height
     raw, labels, segments, what = _load_assets(args)
     p = scene.StateParameters.benchmark().replace(raymarching_step_size=args.step)
@@ -160,9 +200,14 @@ def main(argv=None):
     tt.add_argument("--width", type=int, default=1920); tt.add_argument("--height", type=int, default=1080)
     tt.add_argument("--frames", type=int, default=72); tt.add_argument("--step", type=float, default=0.01)
     tt.add_argument("--out"); tt.add_argument("--keep", type=int, default=6)
+    fl = sub.add_parser("flythrough", help="scripted fly-through: orbit, zoom and every GUI widget over its range")
+    fl.add_argument("--width", type=int, default=1280); fl.add_argument("--height", type=int, default=720)
+    fl.add_argument("--frames", type=int, default=120); fl.add_argument("--out"); fl.add_argument("--keep-every", type=int, default=10)
     args = ap.parse_args(argv)
     if args.command == "benchmark":
         return benchmark(args)
+    if args.command == "flythrough":
+        return flythrough(args)
     if args.command == "turntable":
         return turntable(args)
     if args.command is None:

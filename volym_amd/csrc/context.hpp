@@ -118,6 +118,7 @@ struct volym_ctx {
 
     bool feedback = true;
     bool feedback_frozen = false;               // dev
+    int wide_waves = 0;                         // dev: 0 default choice, 12 or 16 (raymarch.hip launch_march)
     int cost_dilate = -1;                       // radius (8x8 items) of the max-filter over the cost map before dealing; -1: 1 while the view moves, else 0
     bool super_fill = true;
     uint32_t prio_tenths[3] = {3, 6, 10};

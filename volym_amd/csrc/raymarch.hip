@@ -706,6 +706,10 @@ int volym_set_option(volym_ctx* c, int key, int value)
     case 114:   // dilation radius (in 8x8 items) of the cost map when a list is dealt
         c->cost_dilate = std::max(-1, std::min(value, 4));
         return VOLYM_OK;
+    case 115:   // waves per workgroup of the instantiations that need more than 128 VGPRs: 0 default, 12 or 16
+        if (value != 0 && value != 12 && value != 16) return fail(c, VOLYM_E_INVALID, "wide waves: 0, 12 or 16");
+        c->wide_waves = value;
+        return forget_costs(c);
     case 111:   // balancing estimates, dp_share_pct + 1000 * fill_cost
         c->dp_share_pct = static_cast<uint32_t>(value % 1000);
         c->fill_cost = static_cast<uint32_t>(value / 1000);
@@ -929,28 +933,41 @@ static int launch_march(volym_ctx* c)
         // capture this launch's costs?  Only one capture is in flight; a list measured on this very view is final
         const bool capture = plain && c->feedback && !c->feedback_frozen && c->fb_state.load(std::memory_order_acquire) == volym_ctx::FB_IDLE && wl.view_serial != c->view_serial.load(std::memory_order_relaxed);
         uint16_t* cost_out = capture ? c->d_cost : nullptr;
-        const uint32_t want = (n_items + PQ_WAVES - 1) / PQ_WAVES;
-        const uint32_t pgrid = wl.grid ? wl.grid : std::max(1u, std::min(want, max_grid(c)));
         const bool table = !(fp.flags & (F_LINEAR | F_GAUSSIAN));
-#define VOLYM_PQ_LAUNCH(T, KS, I, B, R)                                                                                          \
-    hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT && I, TRACE, KS, I, B, R>), dim3(pgrid), dim3(PQ_THREADS), 0, c->stream, c->d_vol,  \
-                       c->d_imp, c->d_tables, c->d_df, c->d_list[c->cur], n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
         // IMP = false: opacity on and no importance colouring (the common cases), without (IR = false) or with (IR = true)
         // importance rendering; the instrumented launch always takes the general form
         const bool special = !COUNT && !(fp.flags & F_IMP_COLORING) && (fp.flags & F_OPACITY);
         const bool no_imp = special && !(fp.flags & F_IMP_RENDERING);
         const bool ir = special && (fp.flags & F_IMP_RENDERING);
+        // Waves per workgroup of the instantiation (raymarch_pq.h WAVES).  Only the common instantiation fits the 128 VGPRs of a
+        // 16-wave workgroup; the others either run 16 waves and keep 64-100 bytes per lane in scratch, or 12 waves without
+        // scratch.  Measured (profiles/r02_kernel_resources.txt): while the volume is cache resident the fourth wave per SIMD
+        // is worth more than the spills cost (importance 68 vs 71 us, smoothing 134 vs 148, trilinear 113 vs 127); on the
+        // bricked 1024^3 volume with its label map (BASELINE configs[4] on one GPU) the 12-wave form wins (235 vs 259 us).
+        const bool wide12 = c->wide_waves == 12 || (c->wide_waves == 0 && c->bricked && ir);
+        const uint32_t waves = ((table && no_imp) || !wide12) ? PQ_WAVES : PQ_WAVES_WIDE;
+        const uint32_t want = (n_items + waves - 1) / waves;
+        const uint32_t pgrid = wl.grid ? wl.grid : std::max(1u, std::min(want, max_grid(c)));
+#define VOLYM_PQ_LAUNCH(T, KS, I, B, R, WV)                                                                                      \
+    hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT && I, TRACE, KS, I, B, R, WV>), dim3(pgrid), dim3(WV * 64), 0, c->stream, c->d_vol,  \
+                       c->d_imp, c->d_tables, c->d_df, c->d_list[c->cur], n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
+#if VOLYM_DEV_SWITCHES
+#define VOLYM_PQ_LAUNCH_W(T, KS, I, B, R) do { if (wide12) VOLYM_PQ_LAUNCH(T, KS, I, B, R, PQ_WAVES_WIDE); else VOLYM_PQ_LAUNCH(T, KS, I, B, R, PQ_WAVES); } while (0)
+#else
+#define VOLYM_PQ_LAUNCH_W(T, KS, I, B, R) VOLYM_PQ_LAUNCH(T, KS, I, B, R, PQ_WAVES)
+#endif
         if (c->bricked) {
-            if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, true, false);
-            else if (table && ir) VOLYM_PQ_LAUNCH(true, 4, false, true, true);
-            else if (table) VOLYM_PQ_LAUNCH(true, 4, true, true, false);
-            else VOLYM_PQ_LAUNCH(false, 1, true, true, false);
+            if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, true, false, PQ_WAVES);
+            else if (table && ir) { if (wide12) VOLYM_PQ_LAUNCH(true, 4, false, true, true, PQ_WAVES_WIDE); else VOLYM_PQ_LAUNCH(true, 4, false, true, true, PQ_WAVES); }
+            else if (table) VOLYM_PQ_LAUNCH_W(true, 4, true, true, false);
+            else VOLYM_PQ_LAUNCH_W(false, 1, true, true, false);
         } else {
-            if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, false, false);
-            else if (table && ir) VOLYM_PQ_LAUNCH(true, 4, false, false, true);
-            else if (table) VOLYM_PQ_LAUNCH(true, 4, true, false, false);
-            else VOLYM_PQ_LAUNCH(false, 1, true, false, false);
+            if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, false, false, PQ_WAVES);
+            else if (table && ir) VOLYM_PQ_LAUNCH_W(true, 4, false, false, true);
+            else if (table) VOLYM_PQ_LAUNCH_W(true, 4, true, false, false);
+            else VOLYM_PQ_LAUNCH_W(false, 1, true, false, false);
         }
+#undef VOLYM_PQ_LAUNCH_W
 #undef VOLYM_PQ_LAUNCH
         HIPCHK(c, hipGetLastError());
         if (capture) {
@@ -965,7 +982,7 @@ static int launch_march(volym_ctx* c)
             job.view_serial = c->view_serial.load(std::memory_order_relaxed);
             job.continuous = (fp.flags & (F_LINEAR | F_GAUSSIAN)) != 0u;
             job.max_grid = max_grid(c);
-            job.waves = PQ_WAVES;
+            job.waves = waves;
             job.dp_min_cost = c->dp_min_cost;
             job.dp_share_pct = c->dp_share_pct;
             job.fill_cost = c->fill_cost;
@@ -1300,7 +1317,7 @@ int volym_dev_wave_trace(volym_ctx* c, uint32_t* out, uint32_t max_records)
     const WorkList& wl = c->lists[c->cur];
     const uint32_t n_items = static_cast<uint32_t>(wl.entries.size());
     const uint32_t pgrid = wl.grid ? wl.grid : std::max(1u, std::min((n_items + PQ_WAVES - 1) / PQ_WAVES, max_grid(c)));
-    const uint32_t waves = c->kernel_variant == 2 ? pgrid * PQ_WAVES : (c->n_local + 64u * 8u) * 4u;
+    const uint32_t waves = c->kernel_variant == 2 ? pgrid * PQ_WAVES : (c->n_local + 64u * 8u) * 4u;   // PQ_WAVES >= every instantiation's WAVES
     const uint32_t records = waves * 2u;
     if (max_records < records) return fail(c, VOLYM_E_INVALID, "volym_dev_wave_trace: buffer too small");
     HIPCHK(c, hipMalloc(&c->d_trace, static_cast<size_t>(records) * sizeof(uint4)));
@@ -1319,3 +1336,5 @@ int volym_dev_wave_trace(volym_ctx* c, uint32_t* out, uint32_t max_records)
 #endif
 
 }  // extern "C"
+
+#include "mgpu.inc"

@@ -50,8 +50,8 @@
 
 namespace volym {
 
-constexpr int PQ_WAVES = 16;             // waves per workgroup
-constexpr int PQ_THREADS = PQ_WAVES * 64;
+constexpr int PQ_WAVES = 16;             // waves per workgroup of the common instantiation (see WAVES below)
+constexpr int PQ_WAVES_WIDE = 12;        // ... of the instantiations that need more than 128 VGPRs
 constexpr uint32_t PQ_MIN_LEAP_D = 2;    // smallest distance-field value worth a leap
 constexpr int PQ_DP_DEPTH = 2;           // depth-parallel items: samples per lane and iteration (4 lanes per ray)
 constexpr uint32_t PQ_NO_ITEM = 0xffffffffu;   // padding of the work list
@@ -103,8 +103,11 @@ __device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, const H
     if (out_obj) return in_cube ? TILE_FILL_EMPTY : TILE_HIT_TEST;
     return TILE_MARCH;
 }
-template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true, bool BRICK = false, bool IR = false>
-__global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
+// WAVES: waves per workgroup.  16 (four per SIMD, a budget of 128 VGPRs) for the common instantiation, which fits; the
+// importance / continuous-rho instantiations need ~150 registers and run 12 waves (three per SIMD, 168 VGPRs) instead of
+// spilling 64-100 bytes per lane to scratch (profiles/r02_kernel_resources.txt).
+template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true, bool BRICK = false, bool IR = false, int WAVES = PQ_WAVES>
+__global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
     const uint8_t* __restrict__ df4, const uint32_t* __restrict__ order, uint32_t n_items, uint16_t* __restrict__ cost,
     uint32_t* __restrict__ out_shard, uint32_t* __restrict__ out_raster, float4* __restrict__ out_f32,
@@ -124,11 +127,12 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     __shared__ float s_ic_alpha[256];
     __shared__ float s_rho[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_df[VOLYM_DF_LDS_BYTES];
-    __shared__ float4 s_q[PQ_WAVES][PQ_QCAP];            // {pos, w}: one 16-byte LDS access per record
-    __shared__ uint32_t s_qm[PQ_WAVES][PQ_QCAP];
-    __shared__ float s_qr[TABLE ? 1 : PQ_WAVES][TABLE ? 1 : PQ_QCAP];
-    __shared__ uint32_t s_acc[PQ_WAVES][3][64];
-    __shared__ uint8_t s_mail[(IMP || IR) ? PQ_WAVES : 1][(IMP || IR) ? 256 : 1];   // look-ahead candidates of a wave (ahead_straight_wave)
+    constexpr int THREADS = WAVES * 64;
+    __shared__ float4 s_q[WAVES][PQ_QCAP];            // {pos, w}: one 16-byte LDS access per record
+    __shared__ uint32_t s_qm[WAVES][PQ_QCAP];
+    __shared__ float s_qr[TABLE ? 1 : WAVES][TABLE ? 1 : PQ_QCAP];
+    __shared__ uint32_t s_acc[WAVES][3][64];
+    __shared__ uint8_t s_mail[(IMP || IR) ? WAVES : 1][(IMP || IR) ? 256 : 1];   // look-ahead candidates of a wave (ahead_straight_wave)
     __shared__ uint32_t s_next_ticket;
     __shared__ uint32_t s_items[PQ_ITEMS_LDS];          // this workgroup's work list (items b, b+G, ...)
 
@@ -150,9 +154,9 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     {
         const uint32_t i = threadIdx.x;
         if (i == 0u) s_next_ticket = 0u;
-        if (i < PQ_ITEMS_LDS) {
-            const size_t gi = blockIdx.x + static_cast<size_t>(gridDim.x) * i;
-            if (gi < n_items) s_items[i] = order[gi];
+        for (uint32_t k = i; k < PQ_ITEMS_LDS; k += THREADS) {
+            const size_t gi = blockIdx.x + static_cast<size_t>(gridDim.x) * k;
+            if (gi < n_items) s_items[k] = order[gi];
         }
         if (i < 256u) {
             s_tf_tab[i] = tables->tf_tab[i];
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
             const uint4* src = reinterpret_cast<const uint4*>(df4);
             uint4* dst = reinterpret_cast<uint4*>(s_df);
             if (!(VOLYM_DEV_SWITCHES && (fp.dev & 8u)))
-                for (uint32_t k = i; k < n16; k += PQ_THREADS) dst[k] = src[k];
+                for (uint32_t k = i; k < n16; k += THREADS) dst[k] = src[k];
         }
     }
     __syncthreads();
@@ -954,7 +958,7 @@ __global__ __launch_bounds__(PQ_THREADS) void volym_raymarch_pq_kernel(
     if (TRACE) for (int sft = 32; sft > 0; sft >>= 1) trace_accepted += __shfl_xor(trace_accepted, sft, 64);
     if (TRACE && lane == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-        const size_t rec = (static_cast<size_t>(blockIdx.x) * PQ_WAVES + wave) * 2u;
+        const size_t rec = (static_cast<size_t>(blockIdx.x) * WAVES + wave) * 2u;
         trace[rec] = make_uint4(static_cast<uint32_t>(trace_t0), static_cast<uint32_t>(t1 - trace_t0), trace_iters | (trace_tiles << 16), min(trace_flushes, 0xfffu) | (min(trace_marched, 15u) << 12) | (min(trace_dp_iters, 0xffffu) << 16));
         trace[rec + 1] = make_uint4(static_cast<uint32_t>(tm_leap >> 4), static_cast<uint32_t>((tm_samp - tm_flush) >> 4), static_cast<uint32_t>(tm_flush >> 4),
                                     min(trace_lanes, 0xffffu) | (min(trace_accepted, 0xffffu) << 16));   // lanes active at the loop top, samples accepted

@@ -24,6 +24,15 @@ class GpuContext:
         if rc != _lib.OK:
             raise _lib.VolymError(rc, (_lib.lib().volym_last_error(None) or b"").decode())
 
+    @classmethod
+    def borrow(cls, handle, width, height):
+        """A view of a context somebody else owns (the native multi-GPU loop's): close() leaves it alone."""
+        self = cls.__new__(cls)
+        self.width, self.height = int(width), int(height)
+        self._h = handle
+        self._borrowed = True
+        return self
+
     @property
     def handle(self):
         if not self._h:
@@ -36,7 +45,8 @@ class GpuContext:
 
     def close(self):
         if self._h:
-            _lib.lib().volym_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                _lib.lib().volym_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

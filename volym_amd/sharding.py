@@ -66,3 +66,65 @@ def assemble(gathered, W, H, world):
     ok = idx >= 0
     frame[idx[ok]] = tiles[ok]
     return frame.reshape(H, W, 4)
+
+
+# ---- packed shards (volym_pack_shard / volym_assemble_packed, raymarch_kernels.h) ------------------------------------------
+# A packed shard is [header: one (uint32, uint32) pair per shard tile, padded to 1 KiB][1 KiB tiles].  header[t] = (slot, 0)
+# for a tile stored at tiles[slot], or (0xffffffff, value) for a tile whose 256 pixels all equal `value` (not stored).
+PACK_CONSTANT = 0xFFFFFFFF
+
+
+def pack_header_bytes(n_shard_tiles):
+    return (n_shard_tiles * 8 + 1023) & ~1023
+
+
+def packed_shard_bytes(W, H, world, tiles):
+    st = shard_tiles(world, tiling(W, H)[2])
+    return pack_header_bytes(st) + min(int(tiles), st) * 1024
+
+
+def pack_packed(shard, rank, world, W, H, capacity_bytes):
+    """This rank's shard bytes (pack_shard) -> (packed bytes [capacity_bytes], tiles stored, overflow flag).  Slots are
+    handed out in tile order here (the kernel hands them out by an atomic counter: any order, the header says where)."""
+    n_tiles = tiling(W, H)[2]
+    st = shard_tiles(world, n_tiles)
+    nl = local_tiles(rank, world, n_tiles)
+    header_b = pack_header_bytes(st)
+    max_slots = min((capacity_bytes - header_b) // 1024, st)
+    out = np.zeros(capacity_bytes, np.uint8)
+    header = out[: st * 8].view(np.uint32).reshape(st, 2)
+    tiles = np.asarray(shard, np.uint8).reshape(st, 256, 4).view(np.uint32).reshape(st, 256)
+    used, overflow = 0, 0
+    for t in range(nl):
+        px = tiles[t]
+        if (px == px[0]).all():
+            header[t] = (PACK_CONSTANT, px[0])
+        elif used < max_slots:
+            header[t] = (used, 0)
+            out[header_b + used * 1024: header_b + (used + 1) * 1024] = px.view(np.uint8)
+            used += 1
+        else:
+            header[t] = (PACK_CONSTANT, 0)
+            overflow = 1
+    return out, used, overflow
+
+
+def assemble_packed(gathered, stride_bytes, W, H, world):
+    """world packed shards, stride_bytes apart in rank order -> raster [H, W, 4] uint8 (volym_assemble_packed)."""
+    n_tiles = tiling(W, H)[2]
+    st = shard_tiles(world, n_tiles)
+    header_b = pack_header_bytes(st)
+    g = np.asarray(gathered, np.uint8).reshape(-1)
+    idx = _tile_pixel_index(W, H)
+    frame = np.zeros((H * W,), np.uint32)
+    for k in range(n_tiles):
+        r, local = k % world, k // world
+        base = g[r * stride_bytes: (r + 1) * stride_bytes]
+        slot, value = base[: st * 8].view(np.uint32).reshape(st, 2)[local]
+        if slot == PACK_CONSTANT:
+            px = np.full(256, value, np.uint32)
+        else:
+            px = base[header_b + int(slot) * 1024: header_b + (int(slot) + 1) * 1024].view(np.uint32)
+        ok = idx[k] >= 0
+        frame[idx[k][ok]] = px[ok]
+    return frame.view(np.uint8).reshape(H, W, 4)
