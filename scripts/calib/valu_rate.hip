@@ -42,6 +42,30 @@
 #define OP_CVTU(i) "v_cvt_f32_u32 %" #i ", %" #i "\n"
 #define OP_FMIX(i) "v_fma_f32 %" #i ", %8, %9, %" #i "\nv_cvt_flr_i32_f32 %" #i ", %" #i "\n"
 
+#define OP_X25(i) "v_sub_f32 %" #i ", %" #i ", %8\n"
+#define OP_X26(i) "v_fmac_f32 %" #i ", %8, %9\n"
+#define OP_X27(i) "v_sub_u32 %" #i ", %" #i ", %8\n"
+#define OP_X28(i) "v_mov_b32 %" #i ", %8\n"
+#define OP_X29(i) "v_and_b32 %" #i ", %" #i ", %8\n"
+#define OP_X30(i) "v_or_b32 %" #i ", %" #i ", %8\n"
+#define OP_X31(i) "v_xor_b32 %" #i ", %" #i ", %8\n"
+#define OP_X32(i) "v_cvt_f32_i32 %" #i ", %" #i "\n"
+#define OP_X33(i) "v_mul_u32_u24 %" #i ", %" #i ", %8\n"
+#define OP_X34(i) "v_add3_u32 %" #i ", %" #i ", %8, %9\n"
+#define OP_X35(i) "v_lshl_add_u32 %" #i ", %" #i ", 2, %8\n"
+#define OP_X36(i) "v_fma_f32 %" #i ", %" #i ", %10, %8\n"
+#define OP_X37(i) "v_mul_f32 %" #i ", %10, %" #i "\n"
+#define OP_X38(i) "v_min_f32 %" #i ", %" #i ", %8\n"
+#define OP_X39(i) "v_floor_f32 %" #i ", %" #i "\n"
+#define OP_X40(i) "v_cvt_i32_f32 %" #i ", %" #i "\n"
+#define OP_X41(i) "v_fma_f32 %" #i ", %" #i ", 2.0, %8\n"
+#define OP_X42(i) "v_add_f32 %" #i ", 1.0, %" #i "\n"
+#define OP_X43(i) "v_mul_f32 %" #i ", -%" #i ", %8\n"
+#define OP_X44(i) "v_fma_f32 %" #i ", |%" #i "|, %8, %9\n"
+#define OP_X45(i) "v_max3_f32 %" #i ", %" #i ", %8, %9\n"
+#define OP_X46(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\n"
+#define OP_X47(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %9\n"
+#define OP_X48(i) "v_mul_f32 %" #i ", %" #i ", %8\nv_and_b32 %" #i ", %" #i ", %9\n"
 template <int KIND>
 __global__ __launch_bounds__(1024) void rate_kernel(uint32_t* out, float x, float y, uint32_t sc)
 {
@@ -83,6 +107,31 @@ __global__ __launch_bounds__(1024) void rate_kernel(uint32_t* out, float x, floa
             if (KIND == 22) BODY8(OP_BFE)
             if (KIND == 23) BODY8(OP_CVTU)
             if (KIND == 24) BODY8(OP_FMIX)
+            if (KIND == 25) BODY8(OP_X25)
+            if (KIND == 26) BODY8(OP_X26)
+            if (KIND == 27) BODY8(OP_X27)
+            if (KIND == 28) BODY8(OP_X28)
+            if (KIND == 29) BODY8(OP_X29)
+            if (KIND == 30) BODY8(OP_X30)
+            if (KIND == 31) BODY8(OP_X31)
+            if (KIND == 32) BODY8(OP_X32)
+            if (KIND == 33) BODY8(OP_X33)
+            if (KIND == 34) BODY8(OP_X34)
+            if (KIND == 35) BODY8(OP_X35)
+            if (KIND == 36) BODY8(OP_X36)
+            if (KIND == 37) BODY8(OP_X37)
+            if (KIND == 38) BODY8(OP_X38)
+            if (KIND == 39) BODY8(OP_X39)
+            if (KIND == 40) BODY8(OP_X40)
+            if (KIND == 41) BODY8(OP_X41)
+            if (KIND == 42) BODY8(OP_X42)
+            if (KIND == 43) BODY8(OP_X43)
+            if (KIND == 44) BODY8(OP_X44)
+            if (KIND == 45) BODY8(OP_X45)
+            if (KIND == 46) BODY8(OP_X46)
+            if (KIND == 47) BODY8(OP_X47)
+            if (KIND == 48) BODY8(OP_X48)
+
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -123,8 +172,8 @@ __global__ __launch_bounds__(1024) void rate_pk_kernel(uint32_t* out, float x, f
 template <class F>
 static void run(const char* name, F launch, uint32_t* d_out, int n_cus)
 {
-    const int threads_list[4] = {256, 512, 768, 1024};
-    for (int ti = 0; ti < 4; ++ti) {
+    const int threads_list[2] = {512, 1024};
+    for (int ti = 0; ti < 2; ++ti) {
         const int T = threads_list[ti];
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -185,6 +234,31 @@ int main()
     RUN("v_bfe_u32", 22);
     RUN("v_cvt_f32_u32", 23);
     RUN("fma+flr (x2)", 24);
+    RUN("v_sub_f32", 25);
+    RUN("v_fmac_f32", 26);
+    RUN("v_sub_u32", 27);
+    RUN("v_mov_b32", 28);
+    RUN("v_and_b32", 29);
+    RUN("v_or_b32", 30);
+    RUN("v_xor_b32", 31);
+    RUN("v_cvt_f32_i32", 32);
+    RUN("v_mul_u32_u24", 33);
+    RUN("v_add3_u32", 34);
+    RUN("v_lshl_add_u32", 35);
+    RUN("v_fma_f32 sgpr", 36);
+    RUN("v_mul_f32 sgpr", 37);
+    RUN("v_min_f32", 38);
+    RUN("v_floor_f32", 39);
+    RUN("v_cvt_i32_f32", 40);
+    RUN("v_fma_f32 lit", 41);
+    RUN("v_add_f32 inl", 42);
+    RUN("v_mul_f32 neg", 43);
+    RUN("v_fma_f32 abs", 44);
+    RUN("v_max3_f32", 45);
+    RUN("v_add_co_u32", 46);
+    RUN("v_mad_u32_u24 vgpr", 47);
+    RUN("v_mul_f32+v_and mix", 48);
+
 #define RUNPK(NAME, K) run(NAME, [&](int g, int T) { hipLaunchKernelGGL(rate_pk_kernel<K>, dim3(g), dim3(T), 0, 0, d_out, 1.0001f, 0.5f); }, d_out, n_cus)
     RUNPK("v_pk_mul_f32", 0);
     RUNPK("v_pk_fma_f32", 1);

@@ -203,7 +203,14 @@ def main(argv=None):
     fl = sub.add_parser("flythrough", help="scripted fly-through: orbit, zoom and every GUI widget over its range")
     fl.add_argument("--width", type=int, default=1280); fl.add_argument("--height", type=int, default=720)
     fl.add_argument("--frames", type=int, default=120); fl.add_argument("--out"); fl.add_argument("--keep-every", type=int, default=10)
+    dv = sub.add_parser("devtools", help="3D-Slicer .seg.nrrd -> segments.json + label .raw (volym_devtools)")
+    dv.add_argument("nrrd"); dv.add_argument("segments_json"); dv.add_argument("binary_data")
     args = ap.parse_args(argv)
+    if args.command == "devtools":
+        from . import devtools
+        segs, n = devtools.convert(args.nrrd, args.segments_json, args.binary_data)
+        print("devtools: %d segments -> %s, %d label bytes -> %s" % (len(segs), args.segments_json, n, args.binary_data))
+        return 0
     if args.command == "benchmark":
         return benchmark(args)
     if args.command == "flythrough":

@@ -407,6 +407,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
 
         // ---- push the samples flagged by `emit` (any subset of lanes), shade when 64 are waiting ----
         auto append = [&](bool emit, V3 p, float w, uint32_t meta, float rho) __attribute__((always_inline)) {
+            if (VOLYM_DEV_SWITCHES && (fp.dev & 128u)) return;              // timing experiment: nothing is queued or shaded
             const unsigned long long mask = __ballot(emit);
             if (mask == 0ull) return;
             if (emit) {
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         // dependent samples are what a frame ends on).
         auto drain = [&]() __attribute__((always_inline)) { while (q_count >= 64u) flush(64u); };
 
+        if (VOLYM_DEV_SWITCHES && (fp.dev & 256u)) active = false;          // timing experiment: set-up and store only
         if (TRACE) tm_mark = PQ_TICK();
         // ---- at most ONE leap per lane and iteration through provably empty macro cells (both march paths) ----
         // Looking for a leap costs ~100 instructions and an LDS round trip per iteration.  A ray that has just sampled
@@ -817,6 +819,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const bool go = valid && t < t_end && acc_a < 0.95f;             // wgsl:250
+                    if (TRACE && go) trace_accepted++;
                     const bool dense = bs[k] >= fp.thr_byte;                          // <=> b/255 >= thr
                     const bool emit = go && dense && !supp[k];
                     const float w = (1.0f - acc_a) * a_tab[k];                        // wgsl:313-318
