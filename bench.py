@@ -184,6 +184,51 @@ def main():
         ctx = make_context(args, demo, _lib, W, H, local_rank, dims, volume, importances, lut, state)
         frame = torch.empty(W * H * 4, dtype=torch.uint8, device=dev)
         ctx.bind_output(None, frame.data_ptr())
+        # ---- beside the steady state (N = 1), BEFORE the timed region (these ~50 ms of frames also bring the device to its
+        # sustained clocks: a 200-step run from a cold device reads 8 % slower than the steady state it is meant to quote): the first frame of a view nobody has measured (centre-first list, what a
+        # context without cost feedback runs every frame) and a moving view: a turntable of the orbit camera, every frame a new
+        # pose (src/camera.rs:47-61, src/event_loop.rs:100-119), the lists following it through the asynchronous feedback ------
+        if args.kernel == 2 and not args.no_moving_view:
+            from volym_amd import scene
+            ctx.set_option(_lib.OPT_COST_FEEDBACK, 0)
+            ctx.update(state.camera_uniforms(), state.parameter_uniforms())
+            ctx.time_batch(5)
+            first_frame_ms = ctx.time_batch(20) / 20
+            ctx.set_option(_lib.OPT_COST_FEEDBACK, 1)
+            n_tt = args.turntable_frames
+            deg = args.turntable_degrees
+            st2 = scene.State.with_parameters(W / H, scene.StateParameters.benchmark().replace(raymarching_step_size=args.step))
+            views = []
+            for i in range(n_tt + 60):
+                st2.process_mouse(-deg / 0.2, 0.0)                    # sensitivity 0.2 degrees per pixel (src/state.rs:63)
+                st2.update()
+                views.append((st2.camera_uniforms(), st2.parameter_uniforms()))
+            # the steady state of the same views (each rendered until its own list is in place): what "static" means along the path
+            static_ms = []
+            for cu, pu in views[60::max(1, n_tt // 8)][:8]:
+                ctx.update(cu, pu)
+                ctx.time_batch(3)
+                ctx.settle()
+                static_ms.append(ctx.time_batch(10) / 10)
+            static_views_ms = float(np.mean(static_ms))
+            # the turntable itself: one update + compute pass per view, back to back, at most 3 frames ahead of the device (the
+            # back-pressure a swap chain gives the reference's loop, src/event_loop.rs:114)
+            for cu, pu in views[:60]:                                # lead-in: the feedback picks the motion up
+                ctx.update(cu, pu)
+                ctx.compute_pass()
+                ctx.throttle(3)
+            ctx.sync()
+            t1 = time.perf_counter()
+            for cu, pu in views[60:]:
+                ctx.update(cu, pu)
+                ctx.compute_pass()
+                ctx.throttle(3)
+            ctx.sync()
+            moving_view_ms = (time.perf_counter() - t1) / n_tt * 1e3
+            ctx.update(state.camera_uniforms(), state.parameter_uniforms())   # back to the bench view for what follows
+            ctx.time_batch(3)
+            ctx.settle()
+
         for _ in range(args.warmup):
             ctx.compute_pass()
         ctx.sync()
@@ -264,50 +309,6 @@ def main():
             frame_check_result = "MISMATCH: the steady-state frame differs from a fresh context's first frame in %d bytes" % int((first != got).sum())
         else:
             frame_check_result = frame_check(args, dims, volume, importances, lut, state, got)
-
-    # ---- beside the steady state (N = 1): the first frame of a view nobody has measured (centre-first list, what a
-    # context without cost feedback runs every frame) and a moving view: a turntable of the orbit camera, every frame a new
-    # pose (src/camera.rs:47-61, src/event_loop.rs:100-119), the lists following it through the asynchronous feedback ------
-    if world == 1 and args.kernel == 2 and not args.no_moving_view:
-        from volym_amd import scene
-        ctx.set_option(_lib.OPT_COST_FEEDBACK, 0)
-        ctx.update(state.camera_uniforms(), state.parameter_uniforms())
-        ctx.time_batch(5)
-        first_frame_ms = ctx.time_batch(20) / 20
-        ctx.set_option(_lib.OPT_COST_FEEDBACK, 1)
-        n_tt = args.turntable_frames
-        deg = args.turntable_degrees
-        st2 = scene.State.with_parameters(W / H, scene.StateParameters.benchmark().replace(raymarching_step_size=args.step))
-        views = []
-        for i in range(n_tt + 60):
-            st2.process_mouse(-deg / 0.2, 0.0)                    # sensitivity 0.2 degrees per pixel (src/state.rs:63)
-            st2.update()
-            views.append((st2.camera_uniforms(), st2.parameter_uniforms()))
-        # the steady state of the same views (each rendered until its own list is in place): what "static" means along the path
-        static_ms = []
-        for cu, pu in views[60::max(1, n_tt // 8)][:8]:
-            ctx.update(cu, pu)
-            ctx.time_batch(3)
-            ctx.settle()
-            static_ms.append(ctx.time_batch(10) / 10)
-        static_views_ms = float(np.mean(static_ms))
-        # the turntable itself: one update + compute pass per view, back to back, at most 3 frames ahead of the device (the
-        # back-pressure a swap chain gives the reference's loop, src/event_loop.rs:114)
-        for cu, pu in views[:60]:                                # lead-in: the feedback picks the motion up
-            ctx.update(cu, pu)
-            ctx.compute_pass()
-            ctx.throttle(3)
-        ctx.sync()
-        t1 = time.perf_counter()
-        for cu, pu in views[60:]:
-            ctx.update(cu, pu)
-            ctx.compute_pass()
-            ctx.throttle(3)
-        ctx.sync()
-        moving_view_ms = (time.perf_counter() - t1) / n_tt * 1e3
-        ctx.update(state.camera_uniforms(), state.parameter_uniforms())   # back to the bench view for what follows
-        ctx.time_batch(3)
-        ctx.settle()
 
     # ---- roofline of the dominant kernel: HIP events on the kernel's stream, algorithmic bytes from the
     # instrumented launch (reference fetch counts) -------------------------------------------------------

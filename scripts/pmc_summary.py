@@ -31,5 +31,7 @@ for k in sorted(acc):
     if g("SQ_INSTS_VALU") and g("SQ_WAVES"):
         print("  VALU insts per wave            %8.0f ; VMEM_RD per wave %6.0f ; LDS per wave %6.0f" % (
             g("SQ_INSTS_VALU") / g("SQ_WAVES"), g("SQ_INSTS_VMEM_RD", 0) / g("SQ_WAVES"), g("SQ_INSTS_LDS", 0) / g("SQ_WAVES")))
+    if g("TCP_TOTAL_CACHE_ACCESSES_sum") and g("TCP_TCC_READ_REQ_sum") is not None:
+        print("  vector L1 hit rate             %6.1f %%  (1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES)" % (100.0 * (1.0 - g("TCP_TCC_READ_REQ_sum") / g("TCP_TOTAL_CACHE_ACCESSES_sum"))))
     if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
         print("  L2 hit rate                    %6.1f %%" % (100.0 * g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))))

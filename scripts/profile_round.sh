@@ -3,14 +3,14 @@
 # Produces gpurun_out/<tag>/: bench JSON, rocprofv3 --kernel-trace --stats of the same command, and
 # separate --pmc passes for the HBM-side counters of the march kernel.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench rc=$?"; cat $OUT/bench.json
-BENCH="python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-moving-view"    # the steady state only: the first-frame / turntable legs launch the same kernel with other lists
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 echo "stats rc=$?"
 cat $OUT/stats/*/*kernel_stats.csv | cut -c1-220 | head -8

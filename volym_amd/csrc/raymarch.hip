@@ -344,6 +344,23 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
     (void)c;
 }
 
+// device form of a list: {entry, x | y << 16 of the entry's 16x16 tile} (the kernel does no integer division)
+static void list_to_device_form(const volym_ctx* c, const std::vector<uint32_t>& entries, uint32_t* out)
+{
+    for (size_t i = 0; i < entries.size(); ++i) {
+        const uint32_t raw_p = entries[i];
+        uint32_t xy = 0;
+        if (raw_p != PQ_NO_ITEM) {
+            const uint32_t raw = raw_p & ~0x30000000u;
+            const uint32_t lt = (raw >> 31) ? ((raw & 0x7fffffffu) >> 4) : ((raw >> 30) == 1u ? (raw & 0x3fffffffu) : (raw >> 2));
+            const uint32_t tile = lt * c->world + c->rank;
+            xy = (tile % c->tiles_x) | ((tile / c->tiles_x) << 16);
+        }
+        out[2 * i] = raw_p;
+        out[2 * i + 1] = xy;
+    }
+}
+
 // costs by list position -> costs by item
 static void costs_to_items(const WorkList& list, const uint16_t* cost, uint32_t n_entries, std::vector<uint16_t>& item_cost)
 {
@@ -393,9 +410,9 @@ static void feedback_thread(volym_ctx* c)
             if (c->lists[next].entries.size() > c->list_capacity) {
                 job.error = "work list larger than its buffers";    // cannot happen: capacity is the worst case
             } else {
-                std::memcpy(c->h_list_pinned, c->lists[next].entries.data(), c->lists[next].entries.size() * sizeof(uint32_t));
+                list_to_device_form(c, c->lists[next].entries, c->h_list_pinned);
                 // every launch that read d_list[next] finished before the captured launch did (same stream, in order)
-                e = hipMemcpyAsync(c->d_list[next], c->h_list_pinned, c->lists[next].entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream);
+                e = hipMemcpyAsync(c->d_list[next], c->h_list_pinned, c->lists[next].entries.size() * 2u * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream);
                 if (e == hipSuccess) e = hipEventRecord(c->ev_list, c->copy_stream);
                 if (e == hipSuccess) e = hipEventSynchronize(c->ev_list);
             }
@@ -440,10 +457,10 @@ static int rebuild_lists(volym_ctx* c)
         if (c->h_list_pinned) (void)hipHostFree(c->h_list_pinned);
         if (c->h_cost_pinned) (void)hipHostFree(c->h_cost_pinned);
         c->d_cost = nullptr; c->h_list_pinned = nullptr; c->h_cost_pinned = nullptr; c->list_capacity = 0;
-        hipError_t e = hipMalloc(&c->d_list[0], need * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&c->d_list[1], need * sizeof(uint32_t));
+        hipError_t e = hipMalloc(&c->d_list[0], need * 2u * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&c->d_list[1], need * 2u * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&c->d_cost, need * sizeof(uint16_t));
-        if (e == hipSuccess) e = hipHostMalloc(&c->h_list_pinned, need * sizeof(uint32_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(&c->h_list_pinned, need * 2u * sizeof(uint32_t), hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc(&c->h_cost_pinned, need * sizeof(uint16_t), hipHostMallocDefault);
         if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("work lists: ") + hipGetErrorString(e));
         c->list_capacity = need;
@@ -455,8 +472,10 @@ static int rebuild_lists(volym_ctx* c)
     c->lists[0].grid = 0;
     c->lists[0].view_serial = 0;
     c->lists[1] = WorkList();
-    if (!c->geometric.empty())
-        HIPCHK(c, hipMemcpy(c->d_list[0], c->geometric.data(), c->geometric.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!c->geometric.empty()) {
+        list_to_device_form(c, c->geometric, c->h_list_pinned);
+        HIPCHK(c, hipMemcpy(c->d_list[0], c->h_list_pinned, c->geometric.size() * 2u * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     c->lists_ready = true;
     return VOLYM_OK;
 }
@@ -950,7 +969,7 @@ static int launch_march(volym_ctx* c)
         const uint32_t pgrid = wl.grid ? wl.grid : std::max(1u, std::min(want, max_grid(c)));
 #define VOLYM_PQ_LAUNCH(T, KS, I, B, R, WV)                                                                                      \
     hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT && I, TRACE, KS, I, B, R, WV>), dim3(pgrid), dim3(WV * 64), 0, c->stream, c->d_vol,  \
-                       c->d_imp, c->d_tables, c->d_df, c->d_list[c->cur], n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
+                       c->d_imp, c->d_tables, c->d_df, reinterpret_cast<const uint2*>(c->d_list[c->cur]), n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
 #if VOLYM_DEV_SWITCHES
 #define VOLYM_PQ_LAUNCH_W(T, KS, I, B, R) do { if (wide12) VOLYM_PQ_LAUNCH(T, KS, I, B, R, PQ_WAVES_WIDE); else VOLYM_PQ_LAUNCH(T, KS, I, B, R, PQ_WAVES); } while (0)
 #else

@@ -451,6 +451,10 @@ __device__ __forceinline__ bool ahead_cone_wave(const G& g, const FrameParams& f
                     else if (ib[j] >= 128u) hit = true;                           // i/255 >= 0.5  <=>  i >= 128
                 }
             }
+            // a sample is decided as soon as ONE of its eight directions has met an important voxel (wgsl:108-139 returns
+            // there): its other seven lanes stop walking
+            const unsigned long long hit_now = __ballot(hit);
+            if (((hit_now >> (lane & 56u)) & 0xffull) != 0ull) left = true;
             if (__ballot(!left && !hit) == 0ull) break;
         }
         const unsigned long long hits = __ballot(hit);
@@ -555,6 +559,31 @@ __device__ __forceinline__ void replay_saturated(float& t, float t_stop, float b
             t = __uint_as_float((tb & 0xff800000u) | (m2 & 0x7fffffu)); // >= t_stop
         }
     }
+}
+
+// The same shading with the half vector given.  Every sample of a ray sees the eye in the same direction: pos = eye + d*t, so
+// E = normalize(eye - pos) = -d and Hh = normalize(E + L) is a constant of the RAY (wgsl:199-205 recompute it per sample;
+// the values differ by the rounding of pos, ~1e-7).  COLOUR arithmetic.
+__device__ __forceinline__ V3 ray_half_vector(V3 d)
+{
+    const float il = 0.57735026919f;   // normalize(1,1,1)
+    const V3 h = v3(il - d.x, il - d.y, il - d.z);
+    return h * __builtin_amdgcn_rsqf(dot_fast(h, h));
+}
+__device__ __forceinline__ V3 blinn_phong_h(V3 color, V3 grad, V3 Hh)
+{
+    const float g2 = dot_fast(grad, grad);
+    if (!(g2 > 0.0f)) return color;   // zero gradient: normalize gives NaN, length(NaN) > 0 is false
+    const float ginv = __builtin_amdgcn_rsqf(g2);
+    const V3 n = grad * ginv;
+    const float il = 0.57735026919f;
+    const float diffuse = __builtin_fmaxf(0.0f, (n.x + n.y + n.z) * il);
+    float s = __builtin_fmaxf(0.0f, dot_fast(Hh, n));
+    const float s2 = s * s, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8;
+    const float spec = s16 * s8;       // ^24
+    const float kd = __builtin_fmaf(0.7f, diffuse, 0.2f);
+    const float ks = 0.4f * spec;
+    return v3(__builtin_fmaf(color.x, kd, ks), __builtin_fmaf(color.y, kd, ks), __builtin_fmaf(color.z, kd, ks));
 }
 
 // rgba8unorm store: clamp, scale, round to nearest

@@ -109,7 +109,7 @@ __device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, const H
 template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true, bool BRICK = false, bool IR = false, int WAVES = PQ_WAVES>
 __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
-    const uint8_t* __restrict__ df4, const uint32_t* __restrict__ order, uint32_t n_items, uint16_t* __restrict__ cost,
+    const uint8_t* __restrict__ df4, const uint2* __restrict__ order, uint32_t n_items, uint16_t* __restrict__ cost,
     uint32_t* __restrict__ out_shard, uint32_t* __restrict__ out_raster, float4* __restrict__ out_f32,
     Counters* __restrict__ counters, uint4* __restrict__ trace, const FrameParams fp)
 {
@@ -132,9 +132,10 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     __shared__ uint32_t s_qm[WAVES][PQ_QCAP];
     __shared__ float s_qr[TABLE ? 1 : WAVES][TABLE ? 1 : PQ_QCAP];
     __shared__ uint32_t s_acc[WAVES][3][64];
+    __shared__ float4 s_hh[WAVES][64];                  // per ray of the wave's tile: the Blinn-Phong half vector (a constant of the ray)
     __shared__ uint8_t s_mail[(IMP || IR) ? WAVES : 1][(IMP || IR) ? 256 : 1];   // look-ahead candidates of a wave (ahead_straight_wave)
     __shared__ uint32_t s_next_ticket;
-    __shared__ uint32_t s_items[PQ_ITEMS_LDS];          // this workgroup's work list (items b, b+G, ...)
+    __shared__ uint2 s_items[PQ_ITEMS_LDS];             // this workgroup's work list (entries b, b+G, ...): {item code, tile x | tile y << 16}
 
     // IMP = false also pins the opacity flag of the common case so that its tests fold away; every other combination
     // runs the IMP = true instantiation
@@ -187,10 +188,10 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     uint32_t* const acc_r = s_acc[wave][0];
     uint32_t* const acc_g = s_acc[wave][1];
     uint32_t* const acc_b = s_acc[wave][2];
+    float4* const hh = s_hh[wave];
     uint8_t* const mail = s_mail[(IMP || IR) ? wave : 0];
 
     uint32_t n_vol = 0, n_imp = 0, n_steps = 0, n_dense = 0, n_hit = 0;
-    const V3 eye = v3(fp.eye[0], fp.eye[1], fp.eye[2]);
     const float base = fp.base_step, min_step = fp.min_step, thr = fp.thr;
     const float mcf = static_cast<float>(fp.mc_n), inv_mc = 1.0f / mcf;
 
@@ -211,8 +212,12 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         // found expensive, bit 31 | (that id << 2) | quarter: a 4x4 quarter tile marched DEPTH-PARALLEL,
         // four lanes per ray, lane k of a quad taking the k-th speculative sample (see "dp" below)
         const size_t list_pos = blockIdx.x + static_cast<size_t>(gridDim.x) * ticket;     // this entry's place in the work list
-        const uint32_t raw_p = __builtin_amdgcn_readfirstlane(ticket < PQ_ITEMS_LDS ? s_items[ticket] : order[list_pos]);
+        const uint2 entry = ticket < PQ_ITEMS_LDS ? s_items[ticket] : order[list_pos];
+        const uint32_t raw_p = __builtin_amdgcn_readfirstlane(entry.x);
         if (raw_p == PQ_NO_ITEM) continue;
+        // the 16x16 tile's position, worked out by the host when it dealt the list (no integer division here)
+        const uint32_t entry_xy = __builtin_amdgcn_readfirstlane(entry.y);
+        const uint32_t tx = entry_xy & 0xffffu, ty = entry_xy >> 16;
         // counted cost of this list entry, reported by list position (one writer per entry: no atomics, nothing to reset); the
         // host's feedback thread maps positions back to tiles (raymarch.hip, "cost feedback")
         uint32_t entry_cost = 0;
@@ -232,8 +237,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         uint32_t n_sub = 1;
         if (is_super) {
             const uint32_t lt = raw0 & 0x3fffffffu;
-            const uint32_t tile16 = lt * fp.world + fp.rank;
-            const uint32_t tx16 = tile16 % fp.tiles_x, ty16 = tile16 / fp.tiles_x;
+            const uint32_t tx16 = tx, ty16 = ty;
             const uint32_t cls = culling ? classify_tile(fp, hull_edge, lane, static_cast<float>(tx16 * 16u), static_cast<float>(ty16 * 16u), 15.0f) : TILE_MARCH;
             if (cls >= TILE_FILL_EMPTY) {
                 const uint32_t packed = cls == TILE_FILL_MISS ? 0xff000000u : 0u;
@@ -270,8 +274,6 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         const uint32_t quarter = raw & 3u;
         if (is_quarter && !dp && quarter != 0u) continue;   // instrumented launch: quarter 0 stands for the whole tile
         const uint32_t local_tile = item >> 2, sub = item & 3u;
-        const uint32_t tile = local_tile * fp.world + fp.rank;
-        const uint32_t tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
         const uint32_t px_in_sub = dp ? (((quarter & 1u) << 2) + ((lane >> 2) & 3u)) : (lane & 7u);
         const uint32_t py_in_sub = dp ? (((quarter >> 1) << 2) + (lane >> 4)) : (lane >> 3);
         const uint32_t sub_lane = py_in_sub * 8u + px_in_sub;       // position inside the 8x8 sub-tile
@@ -308,6 +310,10 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         ray.o = v3(0.0f, 0.0f, 0.0f); ray.d = v3(0.0f, 0.0f, 0.0f); ray.t_entry = 0.0f; ray.t_exit = 0.0f;
         ray.hit = false;
         if (in_frame) ray = make_ray(fp, gx, gy);
+        {
+            const V3 hvec = ray_half_vector(ray.d);
+            hh[lane] = make_float4(hvec.x, hvec.y, hvec.z, 0.0f);     // (a depth-parallel quad: four equal entries, owner = the first)
+        }
         bool active = in_frame && ray.hit;
         if (COUNT && active) n_hit++;
         float t = active ? ray.t_entry : 0.0f, cur = base, acc_a = active ? 0.0f : 1.0f;   // miss: (0,0,0,1) wgsl:239
@@ -391,7 +397,8 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                               sample_density(g, s_rho, linear, v3(pos.x, pos.y, pos.z + o)) -
                                   sample_density(g, s_rho, linear, v3(pos.x, pos.y, pos.z - o)));
                 }
-                const V3 shaded = blinn_phong(color, grad, pos, eye);   // wgsl:306-311
+                const float4 hv = hh[owner];
+                const V3 shaded = blinn_phong_h(color, grad, v3(hv.x, hv.y, hv.z));   // wgsl:190-211, half vector per ray
                 // w * shaded in 4.28 fixed point; integer adds commute, so arrival order is irrelevant
                 atomicAdd(&acc_r[owner], static_cast<uint32_t>(__builtin_fmaf(shaded.x * w, PQ_FIX_SCALE, 0.5f)));
                 atomicAdd(&acc_g[owner], static_cast<uint32_t>(__builtin_fmaf(shaded.y * w, PQ_FIX_SCALE, 0.5f)));
