@@ -207,8 +207,9 @@ def main():
             static_ms = []
             for cu, pu in views[60::max(1, n_tt // 8)][:8]:
                 ctx.update(cu, pu)
-                ctx.time_batch(3)
-                ctx.settle()
+                for _ in range(2):           # a standing view after a move: a measuring list first, then the final one
+                    ctx.time_batch(3)
+                    ctx.settle()
                 static_ms.append(ctx.time_batch(10) / 10)
             static_views_ms = float(np.mean(static_ms))
             # the turntable itself: one update + compute pass per view, back to back, at most 3 frames ahead of the device (the
@@ -226,8 +227,9 @@ def main():
             ctx.sync()
             moving_view_ms = (time.perf_counter() - t1) / n_tt * 1e3
             ctx.update(state.camera_uniforms(), state.parameter_uniforms())   # back to the bench view for what follows
-            ctx.time_batch(3)
-            ctx.settle()
+            for _ in range(2):
+                ctx.time_batch(3)
+                ctx.settle()
 
         for _ in range(args.warmup):
             ctx.compute_pass()
@@ -312,9 +314,14 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events on the kernel's stream, algorithmic bytes from the
     # instrumented launch (reference fetch counts) -------------------------------------------------------
-    n_ev = min(max(args.steps, 10), 500)
+    # (on a warm device: the untimed checks above left it idle for a second, and a kernel of 35 us read from an idle device is
+    # up to 10 % slower than the same kernel in a sustained run)
+    n_ev = min(max(args.steps, 500), 2000)
     local.time_batch(3)
     local.settle()
+    local.time_batch(3)
+    local.settle()
+    local.time_batch(1500)
     kernel_ms = local.time_batch(n_ev) / n_ev      # HIP events on the kernel's stream, one pair around n_ev launches
     local.sync()
     st = local.stats_pass()

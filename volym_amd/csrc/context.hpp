@@ -22,6 +22,8 @@ struct WorkList {
     std::vector<uint32_t> entries;   // host copy (the feedback thread maps list positions back to tiles)
     uint32_t grid = 0;               // workgroups the list was dealt to (0: the geometric list, any grid)
     uint64_t view_serial = 0;        // the view whose measured costs produced it (0: none, geometric order)
+    bool has_dp = false;             // holds depth-parallel entries (their costs come back as estimates)
+    bool final_for_view = false;     // dealt for a standing view from costs measured on whole entries: no more captures
 };
 
 }  // namespace volym
@@ -101,6 +103,7 @@ struct volym_ctx {
         int list = 0;                            // which of lists[] the captured launch ran
         uint32_t n_entries = 0;
         uint64_t view_serial = 0;
+        bool captured_has_dp = false;
         bool continuous = false;
         uint32_t max_grid = 0, waves = 16;
         int dp_min_cost = -1;

@@ -242,8 +242,13 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
     // further on here.  A maximum filter over the neighbouring 8x8 items (radius job.dilate) makes the list hold for a
     // while: the price is a few tiles split or started early that did not need it.
     std::vector<uint16_t> item_cost(measured_cost);
-    // has the camera moved since the captured frame?  Then the list will be read on yet another view
-    const int dilate = job.dilate >= 0 ? job.dilate : (c->view_serial.load(std::memory_order_relaxed) != job.view_serial ? 1 : 0);
+    // Has the camera moved since the captured frame?  Then the list will be read on yet another view: dilate the costs and
+    // keep split tiles split (hysteresis).  A view that stands still gets exactly what its own costs say -- but only costs
+    // MEASURED on whole 8x8 entries say it well (a split tile reports an estimate).  So when the captured list held split
+    // tiles, the first deal for a standing view is a measuring list without any split, and the deal after it is final.
+    const bool moving = c->view_serial.load(std::memory_order_relaxed) != job.view_serial;
+    const bool measuring = !moving && job.captured_has_dp && job.dp_min_cost < 0;
+    const int dilate = job.dilate >= 0 ? job.dilate : (moving ? 1 : 0);
     if (dilate > 0) {
         const uint32_t gw = c->tiles_x * 2u, gh = c->tiles_y * 2u;
         std::vector<uint16_t> grid(static_cast<size_t>(gw) * gh, 0), tmp(static_cast<size_t>(gw) * gh, 0);
@@ -280,9 +285,10 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
     const uint64_t tenths = job.dp_min_cost < -1 ? static_cast<uint64_t>(-job.dp_min_cost) : (job.continuous ? 12u : 15u);
     const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(64, tenths * total_cost / (10u * resident_waves) + 16));
     const uint32_t dp_thr = job.dp_min_cost < 0 ? adaptive : static_cast<uint32_t>(job.dp_min_cost);
-    const bool dp_ok = job.dp_min_cost != 0;
+    const bool dp_ok = job.dp_min_cost != 0 && !measuring;
     std::vector<std::pair<uint32_t, uint32_t>> keyed;      // (cost share, entry)
     keyed.reserve(geometric.size() * 2);
+    bool has_dp = false;
     // 16x16 tiles whose four sub-tiles were all constant become one "super" fill item (bit 30)
     std::vector<uint8_t> all_fill(n_local, 1), seen(n_local, 0), cnt(n_local, 0);
     for (uint32_t item : geometric) { if (item_cost[item] != 0) all_fill[item >> 2] = 0; cnt[item >> 2]++; }
@@ -294,7 +300,8 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
             item_is_dp[item] = 0;
             continue;
         }
-        const bool split = dp_ok && (k >= dp_thr || (item_is_dp[item] && job.dp_min_cost < 0 && 10u * k >= 7u * dp_thr));
+        const bool split = dp_ok && (k >= dp_thr || (moving && item_is_dp[item] && job.dp_min_cost < 0 && 10u * k >= 7u * dp_thr));
+        has_dp = has_dp || split;
         item_is_dp[item] = split ? 1 : 0;
         if (split)
             for (uint32_t qd = 0; qd < 4; ++qd) keyed.emplace_back((k * job.dp_share_pct + 99u) / 100u, 0x80000000u | (item << 2) | qd);
@@ -341,6 +348,8 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
     }
     out.grid = G;
     out.view_serial = job.view_serial;
+    out.has_dp = has_dp;
+    out.final_for_view = !moving && !measuring;
     (void)c;
 }
 
@@ -949,8 +958,9 @@ static int launch_march(volym_ctx* c)
         const WorkList& wl = c->lists[c->cur];
         const uint32_t n_items = static_cast<uint32_t>(wl.entries.size());
         if (n_items == 0) return VOLYM_OK;
-        // capture this launch's costs?  Only one capture is in flight; a list measured on this very view is final
-        const bool capture = plain && c->feedback && !c->feedback_frozen && c->fb_state.load(std::memory_order_acquire) == volym_ctx::FB_IDLE && wl.view_serial != c->view_serial.load(std::memory_order_relaxed);
+        // capture this launch's costs?  Only one capture is in flight; a list dealt from costs measured on this very view, on
+        // whole 8x8 entries, is final
+        const bool capture = plain && c->feedback && !c->feedback_frozen && c->fb_state.load(std::memory_order_acquire) == volym_ctx::FB_IDLE && (wl.view_serial != c->view_serial.load(std::memory_order_relaxed) || !wl.final_for_view);
         uint16_t* cost_out = capture ? c->d_cost : nullptr;
         const bool table = !(fp.flags & (F_LINEAR | F_GAUSSIAN));
         // IMP = false: opacity on and no importance colouring (the common cases), without (IR = false) or with (IR = true)
@@ -999,6 +1009,7 @@ static int launch_march(volym_ctx* c)
             job.list = c->cur;
             job.n_entries = n_items;
             job.view_serial = c->view_serial.load(std::memory_order_relaxed);
+            job.captured_has_dp = wl.has_dp;
             job.continuous = (fp.flags & (F_LINEAR | F_GAUSSIAN)) != 0u;
             job.max_grid = max_grid(c);
             job.waves = waves;
