@@ -23,10 +23,10 @@
 // Work distribution: persistent workgroups of PQ_WAVES waves, one per CU (it owns the CU's LDS).  Every workgroup reads a
 // list of items -- workgroup b the entries b, b+G, b+2G, ... of `order` -- and its waves draw them through a ticket counter
 // in LDS: dynamic balance inside the workgroup, no global atomics, nothing to reset between launches.  The first frame of
-// a view runs the host's centre-first list (the orbit camera targets the volume centre, src/camera.rs:23) and records a
-// counted cost per tile; from the second frame of an unchanged view the host deals the items longest-processing-time
-// first (raymarch.hip reorder_by_cost), turns the most expensive tiles into depth-parallel quarter items (bit 31) and
-// constant 16x16 tiles into super fill items (bit 30).
+// a context runs the host's centre-first list (the orbit camera targets the volume centre, src/camera.rs:23); a launch can be
+// asked to record a counted cost per list entry, from which a feedback thread on the host deals the next list (raymarch.hip,
+// "cost feedback"): most expensive entries first, the most expensive tiles as depth-parallel quarter items (bit 31),
+// constant 16x16 tiles as super fill items (bit 30).  Entries are {item code, x | y << 16 of the entry's 16x16 tile}.
 //
 // Item kinds and their loops (all bit-identical to the sequential march):
 //   * 8x8 tile, one lane per ray, K speculative samples per iteration ("classic");
