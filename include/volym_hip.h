@@ -26,7 +26,7 @@
  *     volym_assemble_host, volym_stats_pass, volym_time_*; volym_blit blocks only when it has to (re)size its own target.
  *   - the default kernel schedules its work from lists that a feedback thread inside the library re-deals from the
  *     counted cost of earlier frames (asynchronously: a frame never waits for it, and every list renders the same
- *     pixels); volym_settle waits until a re-deal in flight has been adopted.
+ *     pixels); volym_settle runs that loop to its fixed point for the current view.
  */
 #ifndef VOLYM_HIP_H
 #define VOLYM_HIP_H
@@ -152,8 +152,10 @@ int volym_sync(volym_ctx* ctx);
  * enqueued so far and waits until at most `max_in_flight` (1..8) such marks are outstanding.  A loop that runs hundreds of
  * frames ahead of the device also runs hundreds of frames ahead of the cost feedback of its work lists. */
 int volym_throttle(volym_ctx* ctx, uint32_t max_in_flight);
-/* Wait until a re-deal of the work lists that is in flight (cost feedback, see the conventions above) has been adopted:
- * the frames after it run the lists measured on the current view.  Never needed for correctness. */
+/* Bring the cost feedback (see the conventions above) to rest for the current view: waits for a re-deal in flight, then
+ * enqueues frames of the current view itself (exactly what volym_compute_pass enqueues: the output buffers are rewritten
+ * with the same pixels) until the list in use is the final one for this view.  A handful of frames at most; blocks.
+ * The frames after it run at the steady rate of a standing view.  Never needed for correctness. */
 int volym_settle(volym_ctx* ctx);
 
 /* --- output --------------------------------------------------------------------- */

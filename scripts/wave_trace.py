@@ -44,11 +44,20 @@ def main():
         nrec = (ctx.local_tiles() + 1024) * 8
         buf = np.zeros((nrec, 4), np.uint32)
         import time
-        for rep in range(3):
+        wg_ends = []
+        for rep in range(4):
             t_a = time.perf_counter()
             n = L.volym_dev_wave_trace(ctx.handle, buf.ctypes.data_as(C.POINTER(C.c_uint32)), nrec)
             t_b = time.perf_counter()
             assert n > 0, n
+            if args.kernel == 2:
+                rr = buf[0:2 * 4096:2]
+                t0r = rr[:, 0].astype(np.int64)
+                endr = ((t0r - t0r[rr[:, 1] > 0].min()) & 0xFFFFFFFF) + rr[:, 1].astype(np.int64)
+                wg_ends.append(endr.reshape(-1, 16).max(axis=1) / 100.0)
+        if len(wg_ends) >= 3:
+            print("repeatability of the per-workgroup end times over traced launches: corr(2,3) %.2f corr(3,4) %.2f ; std over workgroups %.2f us ; std of the difference (3 - 4) %.2f us" % (
+                np.corrcoef(wg_ends[1], wg_ends[2])[0, 1], np.corrcoef(wg_ends[2], wg_ends[3])[0, 1], wg_ends[3].std(), (wg_ends[2] - wg_ends[3]).std()))
         L.volym_dev_read_costs.restype = C.c_int
         L.volym_dev_read_costs.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.c_uint32]
         L.volym_dev_read_order.restype = C.c_int
@@ -102,6 +111,11 @@ def main():
             tick[slow, 0].sum() / iters[slow].sum(), tick[slow, 1].sum() / iters[slow].sum(), tick[slow, 2].sum() / iters[slow].sum()))
         # per workgroup (16 waves): end time spread
         wg_end = end[: len(end) // 16 * 16].reshape(-1, 16).max(axis=1)
+        st16 = t0[: len(t0) // 16 * 16].reshape(-1, 16)
+        wg_start = st16.min(axis=1)
+        print("workgroup start us (first wave): min %.2f p50 %.2f p90 %.2f max %.2f ; corr(start, end) %.2f ; by XCD (b %% 8) mean start %s mean end %s" % (
+            wg_start.min() / 100, np.percentile(wg_start, 50) / 100, np.percentile(wg_start, 90) / 100, wg_start.max() / 100, np.corrcoef(wg_start, wg_end)[0, 1],
+            [round(float(wg_start[k::8].mean()) / 100, 2) for k in range(8)], [round(float(wg_end[k::8].mean()) / 100, 2) for k in range(8)]))
         print("workgroup end us: min %.1f p50 %.1f p90 %.1f max %.1f" % (wg_end.min() / 100, np.percentile(wg_end, 50) / 100, np.percentile(wg_end, 90) / 100, wg_end.max() / 100))
         has_dp = dp_iters > 0
         print("waves with depth-parallel items: %d ; their duration mean %.1f max %.1f us, dp iterations mean %.1f max %d, all iterations mean %.1f ; us per iteration %.2f" % (

@@ -23,7 +23,10 @@ struct WorkList {
     uint32_t grid = 0;               // workgroups the list was dealt to (0: the geometric list, any grid)
     uint64_t view_serial = 0;        // the view whose measured costs produced it (0: none, geometric order)
     bool has_dp = false;             // holds depth-parallel entries (their costs come back as estimates)
-    bool final_for_view = false;     // dealt for a standing view from costs measured on whole entries: no more captures
+    bool trimmable = false;          // dealt for a standing view from costs measured on whole entries
+    uint32_t trim_round = 0;         // times the list was re-balanced from measured workgroup times since it was dealt
+    bool final_for_view = false;     // trimmable and trimmed as often as asked: no more captures
+    std::vector<uint16_t> shares;    // by list position: the cost share the entry was dealt with (trimmable lists)
 };
 
 }  // namespace volym
@@ -82,8 +85,8 @@ struct volym_ctx {
     // ---- work lists + cost feedback (variant 2) ----
     uint32_t* d_list[2] = {nullptr, nullptr};   // device lists: `cur` is launched from, the other is the feedback thread's
     uint32_t* h_list_pinned = nullptr;          // staging of the list the feedback thread uploads
-    uint16_t* d_cost = nullptr;                 // position-indexed costs of ONE captured launch
-    uint16_t* h_cost_pinned = nullptr;
+    uint16_t* d_cost = nullptr;                 // position-indexed costs of ONE captured launch, then (u32) the end time of every
+    uint16_t* h_cost_pinned = nullptr;          // wave and the start time of every workgroup of that launch (raymarch_pq.h)
     size_t list_capacity = 0;                   // entries each of the above can hold
     int cur = 0;
     volym::WorkList lists[2];
@@ -110,6 +113,8 @@ struct volym_ctx {
         uint32_t dp_share_pct = 60, fill_cost = 2;
         bool super_fill = true, only_quarters = false;
         int dilate = -1;
+        uint32_t grid = 0;                       // workgroups of the captured launch
+        uint32_t trim_rounds = 2;
         double t_us[6] = {};                     // dev: wall-clock stamps of the job's stages
         uint32_t prio_tenths[3] = {3, 6, 10};
         std::string error;                       // worker -> caller
@@ -122,6 +127,7 @@ struct volym_ctx {
     bool feedback = true;
     bool feedback_frozen = false;               // dev
     int wide_waves = 0;                         // dev: 0 default choice, 12 or 16 (raymarch.hip launch_march)
+    uint32_t trim_rounds = 2;                   // re-balancing rounds from measured workgroup times after a standing view's list is dealt
     int cost_dilate = -1;                       // radius (8x8 items) of the max-filter over the cost map before dealing; -1: 1 while the view moves, else 0
     bool super_fill = true;
     uint32_t prio_tenths[3] = {3, 6, 10};

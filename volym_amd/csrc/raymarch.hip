@@ -336,6 +336,7 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
     // list).  Rounds are list rows: entry i sits in row i / G.
     const size_t rows = (static_cast<size_t>(n_keyed) + G - 1) / G;
     out.entries.assign(static_cast<size_t>(G) * rows, PQ_NO_ITEM);
+    out.shares.assign(static_cast<size_t>(G) * rows, 0);
     for (uint32_t i = 0; i < n_keyed; ++i) {
         const std::pair<uint32_t, uint32_t>& kv = keyed[i];
         uint32_t prio = 0;
@@ -344,13 +345,114 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
             prio = k10 >= job.prio_tenths[2] * fair ? 3u : k10 >= job.prio_tenths[1] * fair ? 2u : k10 >= job.prio_tenths[0] * fair ? 1u : 0u;
         }
         const uint32_t row = i / G, j = i - row * G;
-        out.entries[static_cast<size_t>(row) * G + ((row & 1u) ? G - 1u - j : j)] = kv.second | (prio << 28);
+        const size_t pos = static_cast<size_t>(row) * G + ((row & 1u) ? G - 1u - j : j);
+        out.entries[pos] = kv.second | (prio << 28);
+        out.shares[pos] = static_cast<uint16_t>(std::min(65535u, kv.first));
     }
     out.grid = G;
     out.view_serial = job.view_serial;
     out.has_dp = has_dp;
-    out.final_for_view = !moving && !measuring;
-    (void)c;
+    out.trimmable = !moving && !measuring;
+    out.trim_round = 0;
+    out.final_for_view = out.trimmable && job.trim_rounds == 0;
+}
+
+// Re-balance a standing view's list from the times its workgroups took (feedback thread).  The counted costs predict a
+// workgroup's time to within a few percent (profiles/r02_wave_trace.txt: end times spread over ~4 us of 33, and the spread
+// repeats from frame to frame); the frame ends with the LAST workgroup.  So: every workgroup's measured duration gives its
+// own rate (time per unit of cost, for the entries it holds); workgroups that ended after the mean hand entries worth
+// `damp` x their excess to a pool, and the pool goes, largest first, to whichever workgroup is predicted to end first.
+// Scheduling only: the pixels do not change.  Measured (scripts/trim_rounds.py, 1080p bonsai): 33.95 us without, 33.6-33.7 us
+// with 1..8 rounds -- the spread of the end times halves (28.0..34.1 -> 29.7..32.3 us) but their MEAN rises as it does: the
+// workgroups that used to finish early no longer leave the others a quieter machine.  Two rounds; more buys nothing.
+static bool trim_list(const volym_ctx* c, const volym_ctx::FbJob& job, const WorkList& in, const uint32_t* times, WorkList& out)
+{
+    const uint32_t G = in.grid, waves = job.waves;
+    if (G == 0 || G != job.grid || in.entries.size() % G != 0 || in.shares.size() != in.entries.size()) return false;
+    const size_t rows = in.entries.size() / G;
+    const uint32_t* starts = times + static_cast<size_t>(G) * waves;
+    const uint32_t ref = starts[0];
+    int32_t t0 = 0;
+    for (uint32_t b = 0; b < G; ++b) t0 = std::min(t0, static_cast<int32_t>(starts[b] - ref));
+    struct Ent { uint32_t w, code; };
+    std::vector<std::vector<Ent>> wg(G);
+    std::vector<double> dur(G), weight(G, 0.0), rate(G), pred(G);
+    double mean = 0.0;
+    for (uint32_t b = 0; b < G; ++b) {
+        int32_t end = 0;
+        for (uint32_t w = 0; w < waves; ++w) end = std::max(end, static_cast<int32_t>(times[static_cast<size_t>(b) * waves + w] - ref));
+        dur[b] = std::max(1.0, static_cast<double>(end - t0));
+        wg[b].reserve(rows + 8);
+        for (size_t r = 0; r < rows; ++r) {
+            const size_t pos = r * G + b;
+            if (in.entries[pos] == PQ_NO_ITEM) continue;
+            wg[b].push_back(Ent{in.shares[pos] + 1u, in.entries[pos]});
+            weight[b] += in.shares[pos] + 1u;
+        }
+        mean += dur[b];
+    }
+    mean /= G;
+    if (mean > 1.0e6) return false;                        // a second: not a frame's times (counter wrap, garbage)
+    const double damp = 0.8;
+    std::vector<Ent> pool;
+    for (uint32_t b = 0; b < G; ++b) {
+        rate[b] = dur[b] / std::max(1.0, weight[b]);
+        pred[b] = dur[b];
+        double excess = damp * (dur[b] - mean);
+        if (excess <= 0.0) continue;
+        // largest entries that fit first (the list of a workgroup is in order of decreasing share); constant tiles stay
+        std::vector<Ent> keep;
+        keep.reserve(wg[b].size());
+        for (const Ent& e : wg[b]) {
+            const double t = e.w * rate[b];
+            if (e.w > 1u && t <= excess) { pool.push_back(e); excess -= t; pred[b] -= t; }
+            else keep.push_back(e);
+        }
+        wg[b].swap(keep);
+    }
+    std::stable_sort(pool.begin(), pool.end(), [](const Ent& a, const Ent& b) { return a.w > b.w; });
+    for (const Ent& e : pool) {
+        uint32_t best = 0;
+        double best_t = 1.0e300;
+        for (uint32_t b = 0; b < G; ++b) { const double t = pred[b] + e.w * rate[b]; if (t < best_t) { best_t = t; best = b; } }
+        pred[best] = best_t;
+        wg[best].push_back(e);
+    }
+#if VOLYM_DEV_SWITCHES
+    if (std::getenv("VOLYM_TRIM_LOG")) {
+        double mx = 0, mn = 1e300, pmx = 0, pmn = 1e300;
+        for (uint32_t b = 0; b < G; ++b) { mx = std::max(mx, dur[b]); mn = std::min(mn, dur[b]); pmx = std::max(pmx, pred[b]); pmn = std::min(pmn, pred[b]); }
+        std::fprintf(stderr, "trim round %u: workgroup durations min %.2f mean %.2f max %.2f us; %zu entries moved; predicted min %.2f max %.2f\n", in.trim_round + 1, mn / 100, mean / 100,
+                     mx / 100, pool.size(), pmn / 100, pmx / 100);
+        double xs[8] = {}, xw[8] = {}; uint32_t xn[8] = {};
+        for (uint32_t b = 0; b < G; ++b) { xs[b & 7u] += dur[b]; xw[b & 7u] += weight[b]; xn[b & 7u]++; }
+        std::fprintf(stderr, "   by XCD (workgroup %% 8): mean duration");
+        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %.2f", xs[k] / std::max(1u, xn[k]) / 100);
+        std::fprintf(stderr, " ; mean weight");
+        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %.0f", xw[k] / std::max(1u, xn[k]));
+        std::fprintf(stderr, "\n");
+    }
+#endif
+    size_t rows_out = 0;
+    for (uint32_t b = 0; b < G; ++b) {
+        std::stable_sort(wg[b].begin(), wg[b].end(), [](const Ent& a, const Ent& b2) { return a.w > b2.w; });
+        rows_out = std::max(rows_out, wg[b].size());
+    }
+    if (static_cast<size_t>(G) * rows_out > c->list_capacity) return false;
+    out.entries.assign(static_cast<size_t>(G) * rows_out, PQ_NO_ITEM);
+    out.shares.assign(static_cast<size_t>(G) * rows_out, 0);
+    for (uint32_t b = 0; b < G; ++b)
+        for (size_t r = 0; r < wg[b].size(); ++r) {
+            out.entries[r * G + b] = wg[b][r].code;
+            out.shares[r * G + b] = static_cast<uint16_t>(wg[b][r].w - 1u);
+        }
+    out.grid = G;
+    out.view_serial = in.view_serial;
+    out.has_dp = in.has_dp;
+    out.trimmable = true;
+    out.trim_round = in.trim_round + 1;
+    out.final_for_view = out.trim_round >= job.trim_rounds;
+    return true;
 }
 
 // device form of a list: {entry, x | y << 16 of the entry's 16x16 tile} (the kernel does no integer division)
@@ -412,9 +514,19 @@ static void feedback_thread(volym_ctx* c)
         job.t_us[2] = now_us();
         const int next = job.list ^ 1;
         if (e == hipSuccess) {
-            costs_to_items(c->lists[job.list], c->h_cost_pinned, job.n_entries, c->item_cost);
+            // A list dealt for this very view from whole-entry costs is not dealt again (its split tiles report estimates): it is
+            // re-balanced from the workgroups' measured times, job.trim_rounds times.
+            const WorkList& ran = c->lists[job.list];
+            const bool same_view = c->view_serial.load(std::memory_order_relaxed) == job.view_serial && ran.view_serial == job.view_serial;
+            bool trimmed = false;
+            if (same_view && ran.trimmable && ran.trim_round < job.trim_rounds)
+                trimmed = trim_list(c, job, ran, reinterpret_cast<const uint32_t*>(c->h_cost_pinned + ((job.n_entries + 1u) & ~1u)), c->lists[next]);
             job.t_us[3] = now_us();
-            deal_list(c, job, c->item_cost, c->item_is_dp, c->geometric, c->n_local, c->lists[next]);
+            if (!trimmed) {
+                costs_to_items(ran, c->h_cost_pinned, job.n_entries, c->item_cost);
+                job.t_us[3] = now_us();
+                deal_list(c, job, c->item_cost, c->item_is_dp, c->geometric, c->n_local, c->lists[next]);
+            }
             job.t_us[4] = now_us();
             if (c->lists[next].entries.size() > c->list_capacity) {
                 job.error = "work list larger than its buffers";    // cannot happen: capacity is the worst case
@@ -468,9 +580,11 @@ static int rebuild_lists(volym_ctx* c)
         c->d_cost = nullptr; c->h_list_pinned = nullptr; c->h_cost_pinned = nullptr; c->list_capacity = 0;
         hipError_t e = hipMalloc(&c->d_list[0], need * 2u * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&c->d_list[1], need * 2u * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&c->d_cost, need * sizeof(uint16_t));
+        // + the times of the captured launch: a u32 per wave and per workgroup (raymarch_pq.h wg_time)
+        const size_t cost_bytes = (need + 2u) * sizeof(uint16_t) + (static_cast<size_t>(c->n_cus) * 8u * (PQ_WAVES + 1u) + 64u) * sizeof(uint32_t);
+        if (e == hipSuccess) e = hipMalloc(&c->d_cost, cost_bytes);
         if (e == hipSuccess) e = hipHostMalloc(&c->h_list_pinned, need * 2u * sizeof(uint32_t), hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc(&c->h_cost_pinned, need * sizeof(uint16_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(&c->h_cost_pinned, cost_bytes, hipHostMallocDefault);
         if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("work lists: ") + hipGetErrorString(e));
         c->list_capacity = need;
     }
@@ -660,6 +774,18 @@ int volym_settle(volym_ctx* c)
     if (!c) return VOLYM_E_INVALID;
     feedback_quiesce(c);
     if (!c->fb_job.error.empty()) { const std::string m = c->fb_job.error; c->fb_job.error.clear(); return fail(c, VOLYM_E_HIP, m); }
+    // ... and run the feedback to its fixed point for the current view: frames of this view (what volym_compute_pass
+    // enqueues) until the list in use is final -- measuring list, deal, re-balancing rounds (raymarch.hip, "cost feedback")
+    if (c->have_frame && c->kernel_variant == 2 && c->feedback && !c->feedback_frozen && c->lists_ready) {
+        for (int round = 0; round < 12; ++round) {
+            const WorkList& wl = c->lists[c->cur];
+            if (wl.entries.empty() || (wl.view_serial == c->view_serial.load(std::memory_order_relaxed) && wl.final_for_view)) break;
+            int rc = volym::ctx_launch_march(c);
+            if (rc != VOLYM_OK) return rc;
+            feedback_quiesce(c);
+            if (!c->fb_job.error.empty()) { const std::string m = c->fb_job.error; c->fb_job.error.clear(); return fail(c, VOLYM_E_HIP, m); }
+        }
+    }
     return VOLYM_OK;
 }
 
@@ -738,6 +864,10 @@ int volym_set_option(volym_ctx* c, int key, int value)
         if (value != 0 && value != 12 && value != 16) return fail(c, VOLYM_E_INVALID, "wide waves: 0, 12 or 16");
         c->wide_waves = value;
         return forget_costs(c);
+    case 116:   // re-balancing rounds from measured workgroup times (0: the dealt list is final)
+        if (value < 0 || value > 8) return fail(c, VOLYM_E_INVALID, "dev option 116: 0..8");
+        c->trim_rounds = static_cast<uint32_t>(value);
+        return VOLYM_OK;
     case 111:   // balancing estimates, dp_share_pct + 1000 * fill_cost
         c->dp_share_pct = static_cast<uint32_t>(value % 1000);
         c->fill_cost = static_cast<uint32_t>(value / 1000);
@@ -1003,7 +1133,8 @@ static int launch_march(volym_ctx* c)
             // costs -> pinned host memory on the copy stream, behind this launch; the feedback thread takes it from there
             HIPCHK(c, hipEventRecord(c->ev_march, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_march, 0));
-            HIPCHK(c, hipMemcpyAsync(c->h_cost_pinned, c->d_cost, static_cast<size_t>(n_items) * sizeof(uint16_t), hipMemcpyDeviceToHost, c->copy_stream));
+            const size_t cost_bytes = static_cast<size_t>((n_items + 1u) & ~1u) * sizeof(uint16_t) + static_cast<size_t>(pgrid) * (waves + 1u) * sizeof(uint32_t);
+            HIPCHK(c, hipMemcpyAsync(c->h_cost_pinned, c->d_cost, cost_bytes, hipMemcpyDeviceToHost, c->copy_stream));
             HIPCHK(c, hipEventRecord(c->ev_cost, c->copy_stream));
             volym_ctx::FbJob& job = c->fb_job;
             job.list = c->cur;
@@ -1019,6 +1150,8 @@ static int launch_march(volym_ctx* c)
             job.super_fill = c->super_fill;
             job.only_quarters = c->dev_only_quarters;
             job.dilate = c->cost_dilate;
+            job.grid = pgrid;
+            job.trim_rounds = c->trim_rounds;
             job.t_us[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
             for (int i = 0; i < 3; ++i) job.prio_tenths[i] = c->prio_tenths[i];
             {

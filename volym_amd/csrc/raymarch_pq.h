@@ -152,6 +152,10 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     const bool need_imp = imp_coloring || imp_rendering;
 
     if (VOLYM_DEV_SWITCHES && (fp.dev & 16u)) return;                    // launch + dispatch only
+    // A launch whose costs are captured also reports when it ran: behind the costs, the end time of every wave and the start
+    // time of every workgroup (100 MHz counter).  The host evens out what the counted costs mispredict (raymarch.hip, trim_list).
+    uint32_t* const wg_time = reinterpret_cast<uint32_t*>(cost + ((n_items + 1u) & ~1u));
+    if (cost && threadIdx.x == 0u) wg_time[gridDim.x * WAVES + blockIdx.x] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
     {
         const uint32_t i = threadIdx.x;
         if (i == 0u) s_next_ticket = 0u;
@@ -965,6 +969,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
       }
     }
 
+    if (cost && lane == 0) wg_time[blockIdx.x * WAVES + wave] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
     if (TRACE) for (int sft = 32; sft > 0; sft >>= 1) trace_accepted += __shfl_xor(trace_accepted, sft, 64);
     if (TRACE && lane == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
