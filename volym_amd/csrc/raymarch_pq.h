@@ -288,6 +288,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
 
         if (TRACE) { trace_tiles++; tm_mark = PQ_TICK(); }
         uint32_t tile_iters = 0, tile_flushes = 0, tile_trips = 0;   // deterministic cost of this tile, fed back to the scheduler
+        uint32_t trace_ray_iters = 0;                                // TRACE: iterations this lane's ray was active in
         uint32_t tclass = TILE_MARCH;
         if (culling && !dp) {
             tclass = classify_tile(fp, hull_edge, lane, static_cast<float>(tx * 16u + ((sub & 1u) << 3)), static_cast<float>(ty * 16u + ((sub >> 1) << 3)));
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         } else {
         while (__ballot(active) != 0ull) {
             tile_iters++;
-            if (TRACE) { trace_iters++; trace_lanes += static_cast<uint32_t>(__popcll(__ballot(active))); tm_mark = PQ_TICK(); }
+            if (TRACE) { trace_iters++; trace_lanes += static_cast<uint32_t>(__popcll(__ballot(active))); tm_mark = PQ_TICK(); if (active) trace_ray_iters++; }
             leap_phase();
             if (TRACE) { const unsigned long long now = PQ_TICK(); tm_leap += now - tm_mark; tm_mark = now; }
             // ---- 2. K speculative samples: positions under the prediction "class stays last_dense" ----
@@ -950,7 +951,8 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
             if (flags & F_RASTER) {
                 const size_t o = static_cast<size_t>(gy) * fp.W + gx;
                 out_raster[o] = packed;
-                if (flags & F_WRITE_F32) out_f32[o] = make_float4(out_r, out_g, out_b, acc_a);
+                // (traced launch: the f32 frame carries the ray's and the tile's iteration counts instead, scripts/ray_lengths.py)
+                if (flags & F_WRITE_F32) out_f32[o] = TRACE ? make_float4(static_cast<float>(trace_ray_iters), static_cast<float>(tile_iters), out_b, acc_a) : make_float4(out_r, out_g, out_b, acc_a);
             } else {
                 out_shard[static_cast<size_t>(local_tile) * 256u + sub * 64u + sub_lane] = packed;
             }
