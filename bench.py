@@ -259,7 +259,10 @@ def main():
         mg.set_transfer_function(lut)
         mg.update(state.camera_uniforms(), state.parameter_uniforms())
         mg.prepare(0)                       # sizes the packed messages: one untimed frame, maximum over the ranks
-        use_graph = not args.no_graph
+        # HIP-graph replay of the frame cycle: on for one process (virtual ranks, device copies: tested on the 1-GPU box); with one
+        # process per GPU the cycle contains grouped ncclSend/ncclRecv, and capturing those could not be rehearsed on a 1-GPU box
+        # (RCCL refuses two ranks on one device) -- plain enqueues unless VOLYM_MGPU_GRAPH=1 asks for the graph
+        use_graph = (not args.no_graph) and (procs == 1 or os.environ.get("VOLYM_MGPU_GRAPH", "0") == "1")
         mg.run(max(args.warmup, 1), use_graph)
         torch.cuda.synchronize(dev)
         if procs > 1:

@@ -114,7 +114,7 @@ struct volym_ctx {
         bool super_fill = true, only_quarters = false;
         int dilate = -1;
         uint32_t grid = 0;                       // workgroups of the captured launch
-        uint32_t trim_rounds = 2;
+        uint32_t trim_rounds = 0;
         double t_us[6] = {};                     // dev: wall-clock stamps of the job's stages
         uint32_t prio_tenths[3] = {3, 6, 10};
         std::string error;                       // worker -> caller
@@ -127,7 +127,7 @@ struct volym_ctx {
     bool feedback = true;
     bool feedback_frozen = false;               // dev
     int wide_waves = 0;                         // dev: 0 default choice, 12 or 16 (raymarch.hip launch_march)
-    uint32_t trim_rounds = 2;                   // re-balancing rounds from measured workgroup times after a standing view's list is dealt
+    uint32_t trim_rounds = 0;                   // re-balancing rounds from measured workgroup times after a standing view's list is dealt (dev option 116; off: see trim_list)
     int cost_dilate = -1;                       // radius (8x8 items) of the max-filter over the cost map before dealing; -1: 1 while the view moves, else 0
     bool super_fill = true;
     uint32_t prio_tenths[3] = {3, 6, 10};

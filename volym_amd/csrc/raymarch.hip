@@ -364,7 +364,10 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
 // `damp` x their excess to a pool, and the pool goes, largest first, to whichever workgroup is predicted to end first.
 // Scheduling only: the pixels do not change.  Measured (scripts/trim_rounds.py, 1080p bonsai): 33.95 us without, 33.6-33.7 us
 // with 1..8 rounds -- the spread of the end times halves (28.0..34.1 -> 29.7..32.3 us) but their MEAN rises as it does: the
-// workgroups that used to finish early no longer leave the others a quieter machine.  Two rounds; more buys nothing.
+// workgroups that used to finish early no longer leave the others a quieter machine.  In alternating 20 000-frame runs of two
+// builds the gain is 0.1 us (33.17 -> 33.07), and one run in six came out at 33.85: a list trimmed from a capture that caught a
+// hiccup is final, and wrong, for as long as the view stands.  A deterministic list is worth more than 0.3 %: OFF by default
+// (FbJob::trim_rounds = 0; dev option 116 turns it on for experiments).
 static bool trim_list(const volym_ctx* c, const volym_ctx::FbJob& job, const WorkList& in, const uint32_t* times, WorkList& out)
 {
     const uint32_t G = in.grid, waves = job.waves;
