@@ -68,7 +68,9 @@ enum {
     VOLYM_OPT_COST_FEEDBACK = 6, /* 0 = kernel 2 keeps its centre-first work list; default 1 (lists re-dealt from counted costs) */
     VOLYM_OPT_DEPTH_PARALLEL = 7, /* tile cost from which kernel 2 marches a tile as four depth-parallel quarter items:
                                     < 0 adaptive (-N = N/10 x a wave's fair share of the frame; -1 = default), 0 never, > 0 explicit */
-    VOLYM_OPT_XCD_BANDS = 8    /* kernels 0/1: block -> tile remap bands per XCD (0 = identity, default) */
+    VOLYM_OPT_XCD_BANDS = 8,   /* kernels 0/1: block -> tile remap bands per XCD (0 = identity, default) */
+    VOLYM_OPT_REBALANCE_ROUNDS = 9 /* kernel 2: after a standing view's list is dealt, re-balance it this many times (0..8) from
+                                    the times its workgroups took (measured: the list then depends on the weather).  Default 0. */
 };
 
 /* CameraUniforms, byte-for-byte (src/gpu_resources/camera.rs:56-64; WGSL mirror

@@ -24,7 +24,7 @@ def main():
         ctx.update(st.camera_uniforms(), st.parameter_uniforms())
         ctx.time_batch(3000)                       # clocks up
         for rounds in (0, 1, 2, 3, 5, 8, 0, 3):
-            ctx.set_option(116, rounds)
+            ctx.set_option(_lib.OPT_REBALANCE_ROUNDS, rounds)
             ctx.set_option(_lib.OPT_COST_FEEDBACK, 1)      # forgets the costs: geometric list
             ctx.update(st.camera_uniforms(), st.parameter_uniforms())
             ctx.time_batch(3)

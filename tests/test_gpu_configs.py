@@ -64,6 +64,35 @@ def test_timed_path_small(oracle, volym_lib, size, kw):
             _u8_close(f, ref_u8, "frame %d pose %s %s" % (i, pose, kw))
 
 
+def test_rebalanced_lists_render_the_same_frame(oracle, volym_lib):
+    """VOLYM_OPT_REBALANCE_ROUNDS: the list a standing view ends up with after three timing-driven re-balancing rounds (entries
+    moved between workgroups) still renders every pixel: frames equal the first frame and the oracle."""
+    from volym_amd import _lib, demo, scene
+    raw, labels = common.bonsai(128)
+    dims = (128, 128, 128)
+    W, H = 1280, 720
+    cam, par, cu, pu = _uniforms(oracle, W, H)
+    vol_o, imp_o = common.oracle_scene(oracle, raw, labels, common.BONSAI_SEGMENTS, dims)
+    rows = list(range(0, H, 6))
+    _, ref_u8, _ = oracle.render(vol_o, imp_o, dims, oracle.tf_default_lut(), cam, par, W, H, rowlist=rows, want_f32=False)
+    with demo.GpuContext(W, H, 0) as ctx:
+        ctx.set_option(_lib.OPT_REBALANCE_ROUNDS, 3)
+        ctx.set_volume(scene.prepare_volume(raw, dims, True), dims, 0)
+        ctx.set_importances(scene.prepare_volume(scene.map_segments_to_importance(labels, common.BONSAI_SEGMENTS), dims, True), dims)
+        ctx.set_transfer_function(scene.default_lut())
+        ctx.update(cu, pu)
+        ctx.compute_pass()
+        ctx.sync()
+        first = ctx.read_rgba8()
+        ctx.settle()                       # measuring list, deal, three re-balancing rounds
+        for _ in range(3):
+            ctx.compute_pass()
+        ctx.sync()
+        last = ctx.read_rgba8()
+    assert np.array_equal(first, last)
+    _u8_close(last[rows], ref_u8[rows], "re-balanced list")
+
+
 def test_timed_path_bench_workload(oracle, volym_lib):
     """The bench workload itself (bonsai 256^3 @ 1920x1080, benchmark parameters), as bench.py runs it: raster output,
     no float buffer, back-to-back frames of a static view.  Frames 1..5 are identical and every 8th row equals the oracle."""

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("VOLYM_HIP_LIB") or os.path.join(_HERE, "libvolym_hip.
 OK, E_INVALID, E_HIP, E_NO_DEVICE, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 OPT_KERNEL, OPT_WRITE_F32, OPT_MACRO_CELLS = 1, 2, 3
-OPT_VOLUME_LAYOUT, OPT_CULLING, OPT_COST_FEEDBACK, OPT_DEPTH_PARALLEL, OPT_XCD_BANDS = 4, 5, 6, 7, 8
+OPT_VOLUME_LAYOUT, OPT_CULLING, OPT_COST_FEEDBACK, OPT_DEPTH_PARALLEL, OPT_XCD_BANDS, OPT_REBALANCE_ROUNDS = 4, 5, 6, 7, 8, 9
 
 
 class VolymError(RuntimeError):

@@ -127,7 +127,7 @@ struct volym_ctx {
     bool feedback = true;
     bool feedback_frozen = false;               // dev
     int wide_waves = 0;                         // dev: 0 default choice, 12 or 16 (raymarch.hip launch_march)
-    uint32_t trim_rounds = 0;                   // re-balancing rounds from measured workgroup times after a standing view's list is dealt (dev option 116; off: see trim_list)
+    uint32_t trim_rounds = 0;                   // re-balancing rounds from measured workgroup times after a standing view's list is dealt (VOLYM_OPT_REBALANCE_ROUNDS; off: see trim_list)
     int cost_dilate = -1;                       // radius (8x8 items) of the max-filter over the cost map before dealing; -1: 1 while the view moves, else 0
     bool super_fill = true;
     uint32_t prio_tenths[3] = {3, 6, 10};

@@ -367,7 +367,7 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
 // workgroups that used to finish early no longer leave the others a quieter machine.  In alternating 20 000-frame runs of two
 // builds the gain is 0.1 us (33.17 -> 33.07), and one run in six came out at 33.85: a list trimmed from a capture that caught a
 // hiccup is final, and wrong, for as long as the view stands.  A deterministic list is worth more than 0.3 %: OFF by default
-// (FbJob::trim_rounds = 0; dev option 116 turns it on for experiments).
+// (FbJob::trim_rounds = 0; VOLYM_OPT_REBALANCE_ROUNDS turns it on).
 static bool trim_list(const volym_ctx* c, const volym_ctx::FbJob& job, const WorkList& in, const uint32_t* times, WorkList& out)
 {
     const uint32_t G = in.grid, waves = job.waves;
@@ -831,6 +831,10 @@ int volym_set_option(volym_ctx* c, int key, int value)
         if (value < -100 || value > 65535) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_DEPTH_PARALLEL: < 0 adaptive (-N = N/10 x fair share), 0 off, else explicit cost");
         c->dp_min_cost = value;
         return forget_costs(c);
+    case VOLYM_OPT_REBALANCE_ROUNDS:   // 0: the dealt list is final
+        if (value < 0 || value > 8) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_REBALANCE_ROUNDS: 0..8");
+        c->trim_rounds = static_cast<uint32_t>(value);
+        return VOLYM_OK;
     case VOLYM_OPT_XCD_BANDS:
         if (value < 0 || value > 64) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_XCD_BANDS: 0..64");
         c->xcd_bands = static_cast<uint32_t>(value);
@@ -867,10 +871,6 @@ int volym_set_option(volym_ctx* c, int key, int value)
         if (value != 0 && value != 12 && value != 16) return fail(c, VOLYM_E_INVALID, "wide waves: 0, 12 or 16");
         c->wide_waves = value;
         return forget_costs(c);
-    case 116:   // re-balancing rounds from measured workgroup times (0: the dealt list is final)
-        if (value < 0 || value > 8) return fail(c, VOLYM_E_INVALID, "dev option 116: 0..8");
-        c->trim_rounds = static_cast<uint32_t>(value);
-        return VOLYM_OK;
     case 111:   // balancing estimates, dp_share_pct + 1000 * fill_cost
         c->dp_share_pct = static_cast<uint32_t>(value % 1000);
         c->fill_cost = static_cast<uint32_t>(value / 1000);
