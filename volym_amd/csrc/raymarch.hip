@@ -543,7 +543,12 @@ static void feedback_thread(volym_ctx* c)
         }
         if (e != hipSuccess) job.error = std::string("cost feedback: ") + hipGetErrorString(e);
         job.t_us[5] = now_us();
-        c->fb_state.store(volym_ctx::FB_READY, std::memory_order_release);
+        {
+            // under the mutex: a caller in feedback_quiesce that has just found the state CAPTURED must be inside wait() before this
+            // store and its notification happen, or it would sleep through them
+            std::lock_guard<std::mutex> lk(c->fb_mu);
+            c->fb_state.store(volym_ctx::FB_READY, std::memory_order_release);
+        }
         c->fb_cv.notify_all();
     }
 }
