@@ -599,9 +599,8 @@ static int rebuild_lists(volym_ctx* c)
     c->item_cost.assign(static_cast<size_t>(c->n_local) * 4, 0);
     c->item_is_dp.assign(static_cast<size_t>(c->n_local) * 4, 0);
     c->cur = 0;
+    c->lists[0] = WorkList();                 // (no split entries, not final, dealt for no view)
     c->lists[0].entries = c->geometric;
-    c->lists[0].grid = 0;
-    c->lists[0].view_serial = 0;
     c->lists[1] = WorkList();
     if (!c->geometric.empty()) {
         list_to_device_form(c, c->geometric, c->h_list_pinned);
