@@ -223,6 +223,67 @@ def test_random_configurations(oracle, volym_lib, seed):
     assert cases == 36 * 4
 
 
+@pytest.mark.parametrize("cone", [0, 1], ids=["straight", "cone"])
+def test_lookahead_reject_box(oracle, volym_lib, cone):
+    """The look-ahead's reject test (raymarch_device.h ahead_cannot_hit: samples whose probes cannot reach an important voxel are
+    answered without walking them) must never change an answer: compact important regions in the middle, touching the borders
+    (ClampToEdge: open-ended box), none at all, all of it; near and far cameras (a far camera makes the probe segment long and
+    its end point leave the volume), a camera looking straight down (no `right` vector for the cone), 1..64 probes."""
+    from volym_amd import _lib
+    rng = np.random.default_rng(99 + cone)
+    dims = (40, 36, 44)
+    n = dims[0] * dims[1] * dims[2]
+    zz, yy, xx = np.meshgrid(*(np.linspace(0.0, 1.0, d) for d in dims[::-1]), indexing="ij")
+    shell = np.abs(np.sqrt((xx - 0.5) ** 2 + (yy - 0.5) ** 2 + (zz - 0.5) ** 2) - 0.38) < 0.06          # a cup around the middle
+    core = np.sqrt((xx - 0.45) ** 2 + (yy - 0.55) ** 2 + (zz - 0.5) ** 2) < 0.13
+    vol = (np.where(shell, 110, 0) + np.where(core, 200, 0) + rng.integers(0, 6, shell.shape)).astype(np.uint8).ravel()
+    lut = oracle.tf_default_lut()
+
+    def region(x0, x1, y0, y1, z0, z1, value=255, other=60):
+        m = (xx >= x0) & (xx <= x1) & (yy >= y0) & (yy <= y1) & (zz >= z0) & (zz <= z1)
+        return np.where(m, value, other).astype(np.uint8).ravel()
+
+    imps = {
+        "middle": region(0.35, 0.6, 0.4, 0.7, 0.35, 0.65),
+        "corner touching x=0,y=0,z=1": region(0.0, 0.2, 0.0, 0.25, 0.8, 1.0),
+        "slab touching x=1": region(0.9, 1.0, 0.2, 0.8, 0.2, 0.8, value=128, other=127),
+        "none (127 everywhere)": np.full(n, 127, np.uint8),
+        "all": np.full(n, 200, np.uint8),
+        "one voxel": np.where(np.arange(n) == (20 * dims[1] + 18) * dims[0] + 20, 255, 0).astype(np.uint8),
+    }
+    W, H = 88, 56
+    poses = [(0.0, 0.0, 0.0), (35.0, -25.0, 0.6), (140.0, 40.0, 6.0), (0.0, 89.0, 0.3)]
+    for name, imp in imps.items():
+        for pose in poses:
+            cam = oracle.benchmark_camera_uniforms(W / H, *pose)
+            for steps in (1, 15, 64):
+                par = oracle.make_parameters(density_threshold=0.15, use_importance_rendering=1, use_cone_importance_check=cone,
+                                             importance_check_ahead_steps=steps, raymarching_step_size=0.013)
+                ref = oracle.render(vol, imp, dims, lut, cam, par, W, H)
+                with _ctx(W, H) as ctx:
+                    ctx.set_volume(vol, dims, 0)
+                    ctx.set_importances(imp, dims)
+                    ctx.set_transfer_function(lut)
+                    ctx.set_option(_lib.OPT_DEPTH_PARALLEL, 1)
+                    for frame in range(2):
+                        _check(_render_gpu(ctx, cam, par, 2), ref, "importances %s pose %s steps %d cone %d frame %d" % (name, pose, steps, cone, frame))
+    # a camera above the volume looking straight down (up = -z): the centre column's rays run along -y, d.x == d.z == 0 where the
+    # cone has no `right` vector (wgsl:99)
+    import ctypes as C
+    cam_s = oracle.camera_default(W / H)
+    cam_s.position = (C.c_float * 3)(0.5, 2.0, 0.5)
+    cam_s.target = (C.c_float * 3)(0.5, 0.5, 0.5)
+    cam_s.up = (C.c_float * 3)(0.0, 0.0, -1.0)
+    cu = oracle.camera_uniforms(cam_s)
+    par = oracle.make_parameters(use_importance_rendering=1, use_cone_importance_check=cone, importance_check_ahead_steps=9, raymarching_step_size=0.013)
+    ref = oracle.render(vol, imps["middle"], dims, lut, cu, par, W, H)
+    with _ctx(W, H) as ctx:
+        ctx.set_volume(vol, dims, 0)
+        ctx.set_importances(imps["middle"], dims)
+        ctx.set_transfer_function(lut)
+        _check(_render_gpu(ctx, cu, par, 2), ref, "camera above, looking down, cone %d" % cone)
+
+
 def test_ragged_viewport_and_tiny_volume(oracle, volym_lib):
     """Viewport not a multiple of 16 (guard wgsl:217-219), 1-voxel-thin and non-cubic volumes."""
     rng = np.random.default_rng(7)

@@ -43,6 +43,7 @@ struct volym_ctx {
     uint8_t* d_imp = nullptr;
     uint32_t nx = 0, ny = 0, nz = 0;
     uint32_t inx = 0, iny = 0, inz = 0;
+    int imp_box_lo[3] = {1, 1, 1}, imp_box_hi[3] = {0, 0, 0};   // texel AABB of the importances >= 128 (lo > hi: none)
     int filter = VOLYM_FILTER_NEAREST;
     uint8_t lut[256 * 4] = {};
     uint32_t tf_n = 0;

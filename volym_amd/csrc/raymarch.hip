@@ -945,11 +945,41 @@ int volym_set_volume(volym_ctx* c, const uint8_t* voxels, uint32_t nx, uint32_t 
     return forget_costs(c);
 }
 
+// AABB (texel indices) of the importances a look-ahead probe counts as important (byte >= 128, wgsl:133, :155).  Host scan,
+// eight bytes at a time (bit 7 of a byte <=> the byte is >= 128); set-up path.
+static void important_texel_box(const uint8_t* imp, uint32_t nx, uint32_t ny, uint32_t nz, int (&lo)[3], int (&hi)[3])
+{
+    int x0 = INT32_MAX, y0 = INT32_MAX, z0 = INT32_MAX, x1 = -1, y1 = -1, z1 = -1;
+    for (uint32_t z = 0; z < nz; ++z)
+        for (uint32_t y = 0; y < ny; ++y) {
+            const uint8_t* row = imp + (static_cast<size_t>(z) * ny + y) * nx;
+            int first = -1, last = -1;
+            uint32_t x = 0;
+            for (; x + 8u <= nx; x += 8u) {
+                uint64_t w;
+                std::memcpy(&w, row + x, 8);
+                w &= 0x8080808080808080ull;
+                if (!w) continue;
+                if (first < 0) first = static_cast<int>(x) + (__builtin_ctzll(w) >> 3);
+                last = static_cast<int>(x) + 7 - (__builtin_clzll(w) >> 3);
+            }
+            for (; x < nx; ++x)
+                if (row[x] & 0x80u) { if (first < 0) first = static_cast<int>(x); last = static_cast<int>(x); }
+            if (first < 0) continue;
+            x0 = std::min(x0, first); x1 = std::max(x1, last);
+            y0 = std::min(y0, static_cast<int>(y)); y1 = std::max(y1, static_cast<int>(y));
+            z0 = std::min(z0, static_cast<int>(z)); z1 = std::max(z1, static_cast<int>(z));
+        }
+    if (x1 < 0) { lo[0] = lo[1] = lo[2] = 1; hi[0] = hi[1] = hi[2] = 0; return; }
+    lo[0] = x0; lo[1] = y0; lo[2] = z0; hi[0] = x1; hi[1] = y1; hi[2] = z1;
+}
+
 int volym_set_importances(volym_ctx* c, const uint8_t* importances, uint32_t nx, uint32_t ny, uint32_t nz)
 {
     if (!c) return VOLYM_E_INVALID;
     int rc = upload_volume(c, &c->d_imp, importances, nx, ny, nz);
     if (rc != VOLYM_OK) { c->have_imp = false; return rc; }
+    important_texel_box(importances, nx, ny, nz, c->imp_box_lo, c->imp_box_hi);
     c->inx = nx; c->iny = ny; c->inz = nz;
     c->have_imp = true;
     return forget_costs(c);
@@ -1021,6 +1051,16 @@ int volym_update(volym_ctx* c, const volym_camera_uniforms* cam, const volym_par
     fp.nx = c->nx; fp.ny = c->ny; fp.nz = c->nz;
     fp.tiles_x = c->tiles_x; fp.n_tiles = c->n_tiles;
     fp.tf_n = c->tf_n;
+    {
+        // the look-ahead's reject box (raymarch_device.h ahead_cannot_hit): positions u with clamp(floor(u * n), 0, n - 1) inside the
+        // texel AABB of the important voxels, open-ended where the AABB touches the border; 2e-6 covers the rounding of u * n
+        const uint32_t dims[3] = {c->inx, c->iny, c->inz};
+        for (int a = 0; a < 3; ++a) {
+            if (c->imp_box_lo[a] > c->imp_box_hi[a]) { fp.imp_lo[a] = INFINITY; fp.imp_hi[a] = -INFINITY; continue; }
+            fp.imp_lo[a] = c->imp_box_lo[a] <= 0 ? -INFINITY : static_cast<float>(c->imp_box_lo[a]) / static_cast<float>(dims[a]) - 2.0e-6f;
+            fp.imp_hi[a] = c->imp_box_hi[a] >= static_cast<int>(dims[a]) - 1 ? INFINITY : static_cast<float>(c->imp_box_hi[a] + 1) / static_cast<float>(dims[a]) + 2.0e-6f;
+        }
+    }
     const float sigma = 1.5f;            // wgsl:255
     for (int i = -2; i <= 2; ++i) {
         const float x = static_cast<float>(i) * 0.005f;

@@ -53,6 +53,9 @@ struct FrameParams {
     float hull[2][8][4];     // [0] projected unit cube, [1] projected AABB of the occupied macro cells:
                              // up to 8 edges (a, b, c, valid) in pixel units, |(a,b)| = 1, inside: a*x + b*y + c >= 0
     float aabb_lo[3], aabb_hi[3];   // AABB of the occupied macro cells, already grown by its safety margin
+    float imp_lo[3], imp_hi[3];     // positions whose nearest importance texel can be >= 128 (look-ahead probes): the AABB of those
+                                    // texels in texture coordinates, open-ended where it touches the border (ClampToEdge), with its
+                                    // margin; lo > hi: no such texel
     uint32_t dev;            // timing experiments (VOLYM_DEV_SWITCHES): 1 = drop queued samples unshaded, 2 = never leap in dp items
 };
 
@@ -329,6 +332,36 @@ __device__ __forceinline__ bool ahead_straight(const G& g, const FrameParams& fp
     return false;
 }
 
+// Can the look-ahead of the sample at p0 meet an important voxel at all?  Its probes sit at p0 + i * (d * step), i = 1..N,
+// step = (t_exit - |p0|) / N (wgsl:111, :144): on the segment from p0 to p0 + d * (t_exit - |p0|), up to the rounding of N
+// accumulated additions; the cone's eight directions deviate from d by at most 0.2 in length (wgsl:100-113), so their
+// segments end within 0.2 |L| of that end point.  If the bounding box of all that misses the box of the positions that map
+// to important texels (FrameParams::imp_lo/hi), every probe reads an importance < 128 and the shader's loop returns false:
+// the probes need not be walked.  Conservative by construction (any NaN compares false: not rejected); EXACT results.
+__device__ __forceinline__ bool ahead_cannot_hit(const FrameParams& fp, V3 p0, V3 d, float t_exit, bool cone)
+{
+    const float len = __builtin_sqrtf(__builtin_fmaf(p0.x, p0.x, __builtin_fmaf(p0.y, p0.y, p0.z * p0.z)));
+    const float L = t_exit - len;
+    const float aL = __builtin_fabsf(L);
+    const V3 pe = v3(__builtin_fmaf(d.x, L, p0.x), __builtin_fmaf(d.y, L, p0.y), __builtin_fmaf(d.z, L, p0.z));
+    // rounding of the accumulated probe positions (|coordinates| <= len + |L| + 1) and of L itself, plus the cone's spread
+    const float slop = (len + aL + 1.0f) * (static_cast<float>(fp.ahead_steps) + 8.0f) * 2.4e-7f + 1.0e-6f + (cone ? 0.21f * aL : 0.0f);
+    const bool miss = (__builtin_fmaxf(p0.x, pe.x) + slop < fp.imp_lo[0]) | (__builtin_fminf(p0.x, pe.x) - slop > fp.imp_hi[0]) |
+                      (__builtin_fmaxf(p0.y, pe.y) + slop < fp.imp_lo[1]) | (__builtin_fminf(p0.y, pe.y) - slop > fp.imp_hi[1]) |
+                      (__builtin_fmaxf(p0.z, pe.z) + slop < fp.imp_lo[2]) | (__builtin_fminf(p0.z, pe.z) - slop > fp.imp_hi[2]);
+    // a ray along the y axis has no `right` vector (wgsl:99: normalize of a zero cross product): leave those to the probes
+    const bool degenerate = cone && d.x == 0.0f && d.z == 0.0f;
+    // (a second stage -- the segment itself against the box by slab distances -- was measured: it rejects little more on the
+    // reference's benchmark scene and costs 8 % on its straight rows; removed)
+    return miss && !degenerate;
+}
+
+// Can the probe at `p` read an important texel?  (p inside FrameParams::imp_lo/hi; NaN: yes)
+__device__ __forceinline__ bool probe_may_hit(const FrameParams& fp, V3 p)
+{
+    return !((p.x < fp.imp_lo[0]) | (p.x > fp.imp_hi[0]) | (p.y < fp.imp_lo[1]) | (p.y > fp.imp_hi[1]) | (p.z < fp.imp_lo[2]) | (p.z > fp.imp_hi[2]));
+}
+
 // The straight look-ahead of up to K samples per lane, spread over the wave (uninstrumented launches): the samples that
 // need one are numbered across the wave (sample 0 of all lanes first, then sample 1, ...), their owners post
 // (lane, sample) in a 256-byte LDS mailbox, and lane l of round r walks the chain of candidate 64 r + l -- every lane
@@ -336,10 +369,20 @@ __device__ __forceinline__ bool ahead_straight(const G& g, const FrameParams& fp
 // answer by ballot.  Same positions and f32 operations per chain as ahead_straight; a chain's early exit only ever saved
 // fetches.  Every lane of the wave must call this.
 template <int K, class G>
-__device__ __forceinline__ void ahead_straight_wave(const G& g, const FrameParams& fp, const bool (&need)[K], const float (&ts)[K], V3 o, V3 dir,
+__device__ __forceinline__ void ahead_straight_wave(const G& g, const FrameParams& fp, const bool (&need_in)[K], const float (&ts)[K], V3 o, V3 dir,
                                                     float t_exit, uint32_t lane, uint8_t* mail, bool (&found)[K])
 {
     static_assert(K <= 4, "two bits for the sample index");
+    bool need[K];
+    {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { need[k] = need_in[k]; any = any || need[k]; found[k] = false; }
+        if (__ballot(any) == 0ull) return;
+        // samples whose probes cannot reach an important voxel are answered here (false)
+#pragma unroll
+        for (int k = 0; k < K; ++k) need[k] = need[k] && !ahead_cannot_hit(fp, o + dir * ts[k], dir, t_exit, false);
+    }
     uint32_t my_idx[K];
     uint32_t total = 0;
 #pragma unroll
@@ -379,12 +422,20 @@ __device__ __forceinline__ void ahead_straight_wave(const G& g, const FrameParam
         V3 pos = p0;
         bool live = job, hit = false;
         for (int i = 0; i < n; i += VOLYM_PROBE_BATCH) {
-            uint32_t ib[VOLYM_PROBE_BATCH];
+            // the positions are the reference's (accumulated additions); a batch in which no live chain is where an important texel
+            // can be read (outside the box of those texels: the byte is < 128 whatever it is) is not fetched
+            V3 pb[VOLYM_PROBE_BATCH];
+            bool inside = false;
 #pragma unroll
             for (int b = 0; b < VOLYM_PROBE_BATCH; ++b) {
                 pos = pos + ds;
-                ib[b] = g.imp[nearest_offset(g, pos)];                             // clamped offset: safe wherever pos is
+                pb[b] = pos;
+                inside = inside || probe_may_hit(fp, pos);
             }
+            if (__ballot(live && inside) == 0ull) continue;
+            uint32_t ib[VOLYM_PROBE_BATCH];
+#pragma unroll
+            for (int b = 0; b < VOLYM_PROBE_BATCH; ++b) ib[b] = g.imp[nearest_offset(g, pb[b])];   // clamped offset: safe wherever pos is
 #pragma unroll
             for (int b = 0; b < VOLYM_PROBE_BATCH; ++b)
                 if (live && i + b < n && ib[b] >= 128u) { hit = true; live = false; }   // i/255 >= 0.5  <=>  i >= 128
@@ -403,9 +454,11 @@ __device__ __forceinline__ void ahead_straight_wave(const G& g, const FrameParam
 // direction's early exit only ever saved fetches.  `cone_xo`/`cone_yo`: fp.cone_cos/sin[lane & 7] * 0.2, selected once per
 // kernel.  Every lane of the wave must call this (ballots and cross-lane reads inside).
 template <class G>
-__device__ __forceinline__ bool ahead_cone_wave(const G& g, const FrameParams& fp, bool need, V3 start, V3 dir, float t_exit, uint32_t lane,
+__device__ __forceinline__ bool ahead_cone_wave(const G& g, const FrameParams& fp, bool need_in, V3 start, V3 dir, float t_exit, uint32_t lane,
                                                 float cone_xo, float cone_yo)
 {
+    if (__ballot(need_in) == 0ull) return false;
+    const bool need = need_in && !ahead_cannot_hit(fp, start, dir, t_exit, true);   // cannot reach an important voxel: false, unwalked
     const unsigned long long mask = __ballot(need);
     if (mask == 0ull) return false;
     const int n = static_cast<int>(fp.ahead_steps);
@@ -444,6 +497,8 @@ __device__ __forceinline__ bool ahead_cone_wave(const G& g, const FrameParams& f
                 out[j] = outside01(pos);
                 ib[j] = g.imp[nearest_offset(g, pos)];                            // clamped offset: safe wherever pos is
             }
+            // (skipping the batches no direction can read an important texel in, as the straight walk does, was measured here: the
+            // eight directions of a sample seldom agree, and the tests cost 4-14 % on the cone rows)
 #pragma unroll
             for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
                 if (!left && !hit && i + j < n) {
