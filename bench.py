@@ -106,6 +106,8 @@ def make_context(args, demo, _lib, W, H, device, dims, volume, importances, lut,
         ctx.set_option(_lib.OPT_VOLUME_LAYOUT, args.layout)
     if args.xcd_bands >= 0:
         ctx.set_option(_lib.OPT_XCD_BANDS, args.xcd_bands)
+    if args.dp is not None:
+        ctx.set_option(_lib.OPT_DEPTH_PARALLEL, args.dp)
     ctx.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
     ctx.set_importances(importances, dims)
     ctx.set_transfer_function(lut)
@@ -122,6 +124,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--volume", type=int, default=256)
     ap.add_argument("--step", type=float, default=0.01)
+    ap.add_argument("--dp", type=int, default=None, help="VOLYM_OPT_DEPTH_PARALLEL (tuning runs; default: the library's choice)")
     ap.add_argument("--layout", type=int, default=-1, help="volume layout: -1 by size (bricks beyond 64 MiB), 0 linear, 1 4x4x4 bricks")
     ap.add_argument("--kernel", type=int, default=2,
                     help="0 direct (BASELINE configs[1]), 1 macro-cell, 2 persistent workgroups + LDS-staged tables/distance field + shading queue (configs[2], default)")

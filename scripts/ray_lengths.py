@@ -43,6 +43,14 @@ def main():
     marched = t8 > 0
     print("8x8 tiles %d, marched %d; tile iterations (= longest ray): mean %.1f p50 %d p90 %d p99 %d max %d ; sum %d" % (
         len(t8), marched.sum(), t8[marched].mean(), np.percentile(t8[marched], 50), np.percentile(t8[marched], 90), np.percentile(t8[marched], 99), t8.max(), t8.sum()))
+    alpha = f[:, :, 3]
+    a8 = alpha[:Hc, :Wc].reshape(Hc // 8, 8, Wc // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)
+    empty = marched & (a8.max(axis=1) == 0.0)
+    print("marched tiles in which no ray met anything dense (alpha 0 everywhere): %d of %d, %d tile-iterations of %d (%.1f%%); their iterations: %s" % (
+        empty.sum(), marched.sum(), t8[empty].sum(), t8.sum(), 100.0 * t8[empty].sum() / t8.sum(), np.bincount(t8[empty])[:8]))
+    partly = marched & ~empty
+    frac_live = (a8[partly] > 0).mean()
+    print("in the other marched tiles %.0f%% of the rays meet something dense" % (100 * frac_live))
     total_iters = t8.sum()
     fair = total_iters / 4096.0
     for mult in (1.0, 1.5, 2.0):

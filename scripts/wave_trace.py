@@ -39,6 +39,9 @@ def main():
         ctx.set_option(_lib.OPT_KERNEL, args.kernel)
         ctx.set_option(_lib.OPT_XCD_BANDS if args.kernel != 2 else 101, args.bands if args.kernel != 2 else max(args.bands, 1))
         ctx.set_option(114, 0)
+        for kv in os.environ.get("VOLYM_DEV_OPTS", "").split(","):        # e.g. VOLYM_DEV_OPTS=117=0,116=2
+            if "=" in kv:
+                ctx.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
         ctx.update(state.camera_uniforms(), state.parameter_uniforms())
         ctx.stats_pass()
         nrec = (ctx.local_tiles() + 1024) * 8

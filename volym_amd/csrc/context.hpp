@@ -66,6 +66,17 @@ struct volym_ctx {
     uint32_t mc_n = 32;
     uint32_t df_thr_byte = 0xffffffffu;
     uint32_t thr_byte_cull = 256;
+    uint32_t* d_tile_mask = nullptr;         // one bit per 8x8 pixel tile: some occupied macro cell projects onto it (per view); two
+                                             // buffers of tile_mask_words: the one in use and the one being kept zeroed for the next view
+    int mask_cur = 0;
+    uint32_t tile_mask_words = 0;            // 0: the frame has more tiles than the mask kernel holds in LDS -- no mask
+    bool tile_mask = true;                   // dev switch
+    bool mask_wanted = false;                // compute_culling: this view gets a mask
+    bool mask_pending = false;               // ... and has not got it yet
+    bool mask_eager = false;                 // dev
+    uint32_t view_launches = 0;              // launches since the view last changed
+    float mask_clip[16] = {};                // world -> clip of the view (f32 copy for the mask kernel)
+    float mask_margin = 0.0f;
     int* d_aabb = nullptr;                   // written by the distance-field kernel (kept for the dev tools)
 
     uint32_t* d_shard_own = nullptr;
@@ -115,6 +126,8 @@ struct volym_ctx {
         bool super_fill = true, only_quarters = false;
         int dilate = -1;
         uint32_t grid = 0;                       // workgroups of the captured launch
+        uint32_t dev_drop_tenths = 0;            // dev
+        uint32_t dp_floor = 104;
         uint32_t trim_rounds = 0;
         double t_us[6] = {};                     // dev: wall-clock stamps of the job's stages
         uint32_t prio_tenths[3] = {3, 6, 10};
@@ -133,6 +146,8 @@ struct volym_ctx {
     bool super_fill = true;
     uint32_t prio_tenths[3] = {3, 6, 10};
     bool dev_only_quarters = false;
+    uint32_t dev_drop_tenths = 0;
+    uint32_t dp_floor = 104;                     // floor of the adaptive split threshold, cost units (deal_list)
     bool bricked = false;
     uint64_t brick_from_bytes = 64ull << 20;
     int layout_choice = -1;

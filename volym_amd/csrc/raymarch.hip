@@ -145,6 +145,7 @@ static void compute_culling(volym_ctx* c)
     fp.cull = 0;
     std::memset(fp.hull, 0, sizeof fp.hull);
     c->hull_dirty = false;
+    c->mask_wanted = false;
     if (!c->culling) return;
     // AABB of the occupied cells (per threshold byte, computed when the volume was set), grown by what a sample may
     // reach beyond its own position
@@ -189,6 +190,12 @@ static void compute_culling(volym_ctx* c)
     const double c0[3] = {0, 0, 0}, c1[3] = {1, 1, 1};
     if (project_box(c0, c1, fp.hull[0])) fp.cull |= CULL_CUBE_HULL;
     if (!none && project_box(lo, hi, fp.hull[1])) fp.cull |= CULL_OBJ_HULL;
+    // the per-tile mask of the occupied cells' projections (volym_tile_mask_kernel): its cells lie inside the AABB whose
+    // corners were all found in front of the eye, so their corners are too
+    fp.mask_t8x = c->tiles_x * 2u;
+    c->mask_margin = static_cast<float>(margin);
+    for (int i = 0; i < 16; ++i) c->mask_clip[i] = static_cast<float>(M[i]);
+    c->mask_wanted = (fp.cull & CULL_OBJ_HULL) != 0u && c->tile_mask && c->tile_mask_words != 0u;
 }
 // ================================================================================================================
 // Work lists and their cost feedback (variant 2).
@@ -283,7 +290,12 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
     // measured optimum: 1.5x for the table mode, 1.2x for the continuous-rho modes (their classic loop speculates only two
     // samples deep, a depth-parallel item four)
     const uint64_t tenths = job.dp_min_cost < -1 ? static_cast<uint64_t>(-job.dp_min_cost) : (job.continuous ? 12u : 15u);
-    const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(64, tenths * total_cost / (10u * resident_waves) + 16));
+    // ... but never below the cost of a tile whose one wave takes about as long as the shortest frame this kernel renders: when
+    // culling leaves little other work (the fair share shrinks), splitting more tiles only adds work, it does not shorten
+    // the tiles that are already as fast as they get (scripts/dp_sweep.py: the optimum stayed at ~96 units, with or without the
+    // tile mask, while the fair share went from 53 to 40)
+    const uint64_t floor_cost = (job.dp_min_cost == -1 && !job.continuous) ? job.dp_floor : 64u;
+    const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(floor_cost, tenths * total_cost / (10u * resident_waves) + 16));
     const uint32_t dp_thr = job.dp_min_cost < 0 ? adaptive : static_cast<uint32_t>(job.dp_min_cost);
     const bool dp_ok = job.dp_min_cost != 0 && !measuring;
     std::vector<std::pair<uint32_t, uint32_t>> keyed;      // (cost share, entry)
@@ -300,6 +312,7 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
             item_is_dp[item] = 0;
             continue;
         }
+        if (job.dev_drop_tenths && static_cast<uint64_t>(k) * 10u * resident_waves >= static_cast<uint64_t>(job.dev_drop_tenths) * total_cost) { item_is_dp[item] = 0; continue; }   // dev: what if the longest tiles were not there?
         const bool split = dp_ok && (k >= dp_thr || (moving && item_is_dp[item] && job.dp_min_cost < 0 && 10u * k >= 7u * dp_thr));
         has_dp = has_dp || split;
         item_is_dp[item] = split ? 1 : 0;
@@ -708,6 +721,13 @@ int volym_create(volym_ctx** out, uint32_t width, uint32_t height, int device_id
     if ((e = hipMalloc(&c->d_counters, sizeof(Counters))) != hipSuccess) return bail(e, "hipMalloc(counters)");
     if ((e = hipMemset(c->d_frame_own, 0, frame_bytes)) != hipSuccess) return bail(e, "hipMemset(frame)");
     if ((e = hipMalloc(&c->d_aabb, 6 * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(aabb)");
+    {
+        const uint64_t tiles8 = static_cast<uint64_t>(c->tiles_x) * 2u * c->tiles_y * 2u;
+        const uint64_t words = (tiles8 + 31u) / 32u;
+        c->tile_mask_words = words <= VOLYM_TILE_MASK_MAX_WORDS ? static_cast<uint32_t>(words) : 0u;
+        if (c->tile_mask_words && (e = hipMalloc(&c->d_tile_mask, 2u * c->tile_mask_words * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(tile mask)");
+        if (c->tile_mask_words && (e = hipMemset(c->d_tile_mask, 0, 2u * c->tile_mask_words * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMemset(tile mask)");
+    }
     if ((e = hipMalloc(&c->d_pack_counters, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pack counters)");
     if ((e = hipMemset(c->d_pack_counters, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMemset(pack counters)");
     for (int i = 0; i < volym_ctx::TABLE_RING; ++i) {
@@ -749,7 +769,7 @@ void volym_destroy(volym_ctx* c)
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     (void)hipFree(c->d_vol); (void)hipFree(c->d_imp); (void)hipFree(c->d_tables); (void)hipFree(c->d_mc); (void)hipFree(c->d_df);
     (void)hipFree(c->d_shard_own); (void)hipFree(c->d_frame_own); (void)hipFree(c->d_f32); (void)hipFree(c->d_blit);
-    (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_pack_counters); (void)hipFree(c->d_counters); (void)hipFree(c->d_aabb);
+    (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_pack_counters); (void)hipFree(c->d_counters); (void)hipFree(c->d_aabb); (void)hipFree(c->d_tile_mask);
     (void)hipFree(c->d_list[0]); (void)hipFree(c->d_list[1]); (void)hipFree(c->d_cost);
     if (c->h_list_pinned) (void)hipHostFree(c->h_list_pinned);
     if (c->h_cost_pinned) (void)hipHostFree(c->h_cost_pinned);
@@ -874,6 +894,17 @@ int volym_set_option(volym_ctx* c, int key, int value)
     case 115:   // waves per workgroup of the instantiations that need more than 128 VGPRs: 0 default, 12 or 16
         if (value != 0 && value != 12 && value != 16) return fail(c, VOLYM_E_INVALID, "wide waves: 0, 12 or 16");
         c->wide_waves = value;
+        return forget_costs(c);
+    case 119:   // floor of the adaptive split threshold (cost units)
+        c->dp_floor = static_cast<uint32_t>(std::max(value, 1));
+        return forget_costs(c);
+    case 118:   // drop the tiles of >= value/10 x the fair share from the lists (the frame is then incomplete): how much do they cost?
+        c->dev_drop_tenths = static_cast<uint32_t>(std::max(value, 0));
+        return forget_costs(c);
+    case 117:   // 0: no per-view tile mask (the hulls and the AABB clip stay); 2: a mask for every view, on its first frame
+        c->tile_mask = value != 0;
+        c->mask_eager = value == 2;
+        c->hull_dirty = true;
         return forget_costs(c);
     case 111:   // balancing estimates, dp_share_pct + 1000 * fill_cost
         c->dp_share_pct = static_cast<uint32_t>(value % 1000);
@@ -1010,7 +1041,34 @@ static int ensure_frame_resources(volym_ctx* c)
         c->df_thr_byte = c->thr_byte_cull;
         c->hull_dirty = true;
     }
-    if (c->hull_dirty) compute_culling(c);
+    if (c->hull_dirty) {
+        compute_culling(c);
+        c->fp.tile_mask = nullptr;
+        c->fp.mask_words = c->tile_mask_words;
+        c->fp.tile_mask_spare = c->d_tile_mask ? c->d_tile_mask + static_cast<size_t>(c->mask_cur ^ 1) * c->tile_mask_words : nullptr;
+        c->mask_pending = c->mask_wanted;
+        c->view_launches = 0;
+    }
+    // The tile mask costs a kernel per view (~5 us + the gap before the march).  A frame of 4 Mpixels and more saves several
+    // times that on its first frame already; a 1080p frame saves ~1 us per frame (it is bound by its longest tiles, not by
+    // the work the mask removes): there the mask is built when a view is rendered a second time, so that a moving camera
+    // never pays for it (turntable: 52 us per frame without, 62 with a mask per view).
+    if (c->mask_pending && (c->view_launches >= 1u || static_cast<uint64_t>(c->W) * c->H >= (4ull << 20) || c->mask_eager)) {
+        ClipMatrix M;
+        std::memcpy(M.m, c->mask_clip, sizeof M.m);
+        // into the buffer the launches so far have kept zeroed; the launches from here on read it and zero the other one
+        c->mask_cur ^= 1;
+        uint32_t* cur = c->d_tile_mask + static_cast<size_t>(c->mask_cur) * c->tile_mask_words;
+        const uint32_t cells = c->mc_n * c->mc_n * c->mc_n;
+        hipLaunchKernelGGL(volym_tile_mask_kernel, dim3((cells + 255u) / 256u), dim3(256), 0, c->stream, c->d_mc, c->mc_n, c->thr_byte_cull, M, c->mask_margin,
+                           c->W, c->H, c->tiles_x * 2u, c->tile_mask_words, cur);
+        HIPCHK(c, hipGetLastError());
+        c->fp.tile_mask = cur;
+        c->fp.cull |= CULL_TILE_MASK;
+        c->fp.tile_mask_spare = c->d_tile_mask + static_cast<size_t>(c->mask_cur ^ 1) * c->tile_mask_words;
+        c->mask_pending = false;
+    }
+    c->view_launches++;
     return VOLYM_OK;
 }
 
@@ -1098,11 +1156,12 @@ int volym_update(volym_ctx* c, const volym_camera_uniforms* cam, const volym_par
     } else {
         c->thr_byte_cull = tb;
     }
-    if (!c->have_frame || std::memcmp(&c->cam_copy, cam, sizeof *cam) != 0 || std::memcmp(&c->par_copy, par, sizeof *par) != 0)
+    if (!c->have_frame || std::memcmp(&c->cam_copy, cam, sizeof *cam) != 0 || std::memcmp(&c->par_copy, par, sizeof *par) != 0) {
         c->view_serial.fetch_add(1, std::memory_order_relaxed);   // the lists stay valid (they are scheduling only); the feedback follows the view
+        c->hull_dirty = true;                                     // hulls, AABB clip and tile mask belong to the view
+    }
     c->cam_copy = *cam;
     c->par_copy = *par;
-    c->hull_dirty = true;
     c->have_frame = true;
     return VOLYM_OK;
 }
@@ -1198,6 +1257,8 @@ static int launch_march(volym_ctx* c)
             job.only_quarters = c->dev_only_quarters;
             job.dilate = c->cost_dilate;
             job.grid = pgrid;
+            job.dev_drop_tenths = c->dev_drop_tenths;
+            job.dp_floor = c->dp_floor;
             job.trim_rounds = c->trim_rounds;
             job.t_us[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
             for (int i = 0; i < 3; ++i) job.prio_tenths[i] = c->prio_tenths[i];

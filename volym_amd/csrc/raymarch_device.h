@@ -57,6 +57,12 @@ struct FrameParams {
                                     // texels in texture coordinates, open-ended where it touches the border (ClampToEdge), with its
                                     // margin; lo > hi: no such texel
     uint32_t dev;            // timing experiments (VOLYM_DEV_SWITCHES): 1 = drop queued samples unshaded, 2 = never leap in dp items
+    uint32_t mask_t8x;       // 8x8 tiles per row of tile_mask
+    const uint32_t* tile_mask;   // CULL_TILE_MASK: one bit per 8x8 pixel tile of the frame: set when the projection of some occupied macro
+                                 // cell covers a pixel of it (volym_tile_mask_kernel, once per view); a clear bit: no ray of the tile can
+                                 // meet anything dense
+    uint32_t* tile_mask_spare;   // the mask buffer this view does not use: every launch zeroes it for the next view's mask kernel
+    uint32_t mask_words;
 };
 
 #ifndef VOLYM_DEV_SWITCHES
@@ -68,6 +74,7 @@ enum : uint32_t {
     CULL_OBJ_HULL = 1u << 1,    // hull[1] is usable
     CULL_AABB = 1u << 2,        // aabb_lo/hi are valid: no sample outside it can reach the threshold
     CULL_NOTHING_DENSE = 1u << 3,   // no macro cell can reach the threshold at all
+    CULL_TILE_MASK = 1u << 4,   // tile_mask is valid for this view
 };
 
 // Per-(transfer function, parameters) tables, built on the host with the same wgsl_math.h

@@ -361,6 +361,68 @@ __global__ __launch_bounds__(1024) void volym_distance_field_kernel(const uint8_
     if (r < 6u) aabb[r] = s_box[r];
 }
 
+// Which 8x8 pixel tiles can see anything dense?  Every macro cell that may hold a voxel >= thr_byte (the criterion of the
+// distance field and of the AABB) is projected -- its box grown by `margin` in texture space, the bounding rectangle of its
+// eight corners grown by 1.5 pixels, as the hulls are -- and the tiles with a pixel inside get their bit.  A ray meets a dense
+// sample only inside such a cell, and the ray of pixel (gx, gy) passes through the point (gx, gy) of the projection
+// (wgsl:221-229), so a tile without its bit is constant.  One thread per cell, bits set with atomicOr into a mask that the
+// march kernel keeps cleared (it zeroes the buffer it is not reading, see volym_raymarch_pq_kernel); a bit left over from an
+// earlier view only costs the march of a tile, never a pixel.  Launched once per view, in stream order (raymarch.hip
+// ensure_frame_resources).  The caller guarantees w > 0 for every corner (the AABB of the occupied cells projected with all
+// its corners in front of the eye: CULL_OBJ_HULL); a cell with a corner that is not sets every bit.
+struct ClipMatrix { float m[16]; };   // world -> clip, column-major
+constexpr uint32_t VOLYM_TILE_MASK_MAX_WORDS = 1u << 20;     // 32 M tiles of 8x8 pixels
+__global__ __launch_bounds__(256) void volym_tile_mask_kernel(const uint8_t* __restrict__ mc_max, uint32_t mc_n, uint32_t thr_byte, ClipMatrix M,
+                                                              float margin, uint32_t W, uint32_t H, uint32_t t8x, uint32_t n_words,
+                                                              uint32_t* __restrict__ out)
+{
+    const uint32_t cell = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t cells = mc_n * mc_n * mc_n;
+    if (cell >= cells || mc_max[cell] < thr_byte) return;
+    const float inv = 1.0f / static_cast<float>(mc_n);
+    const float fw = static_cast<float>(W), fh = static_cast<float>(H);
+    const uint32_t cx = cell % mc_n, cy = (cell / mc_n) % mc_n, cz = cell / (mc_n * mc_n);
+    const float lo[3] = {static_cast<float>(cx) * inv - margin, static_cast<float>(cy) * inv - margin, static_cast<float>(cz) * inv - margin};
+    const float hi[3] = {static_cast<float>(cx + 1u) * inv + margin, static_cast<float>(cy + 1u) * inv + margin, static_cast<float>(cz + 1u) * inv + margin};
+    float px0 = 3.0e38f, px1 = -3.0e38f, py0 = 3.0e38f, py1 = -3.0e38f;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float x = (k & 1) ? hi[0] : lo[0], y = (k & 2) ? hi[1] : lo[1], z = (k & 4) ? hi[2] : lo[2];
+        const float qx = M.m[0] * x + M.m[4] * y + M.m[8] * z + M.m[12];
+        const float qy = M.m[1] * x + M.m[5] * y + M.m[9] * z + M.m[13];
+        const float qw = M.m[3] * x + M.m[7] * y + M.m[11] * z + M.m[15];
+        if (!(qw > 0.0f)) bad = true;
+        const float iw = 1.0f / qw;
+        const float sx = (qx * iw + 1.0f) * 0.5f * fw, sy = (1.0f - qy * iw) * 0.5f * fh;
+        if (!(sx == sx) || !(sy == sy)) bad = true;
+        px0 = fminf(px0, sx); px1 = fmaxf(px1, sx); py0 = fminf(py0, sy); py1 = fmaxf(py1, sy);
+    }
+    if (bad) {                                   // cannot happen under CULL_OBJ_HULL; be safe: everything is marched
+        for (uint32_t i = 0; i < n_words; ++i) atomicOr(&out[i], 0xffffffffu);
+        return;
+    }
+    // pixels (integer points) inside the grown rectangle; a relative 1e-5 for the f32 projection
+    const float gx = 1.5f + 1.0e-5f * fw, gy = 1.5f + 1.0e-5f * fh;
+    const float fx0 = fmaxf(ceilf(px0 - gx), 0.0f), fx1 = fminf(floorf(px1 + gx), fw - 1.0f);
+    const float fy0 = fmaxf(ceilf(py0 - gy), 0.0f), fy1 = fminf(floorf(py1 + gy), fh - 1.0f);
+    if (!(fx0 <= fx1) || !(fy0 <= fy1)) return;          // off screen
+    const uint32_t tx0 = static_cast<uint32_t>(fx0) >> 3, tx1 = static_cast<uint32_t>(fx1) >> 3;
+    const uint32_t ty0 = static_cast<uint32_t>(fy0) >> 3, ty1 = static_cast<uint32_t>(fy1) >> 3;
+    for (uint32_t ty = ty0; ty <= ty1; ++ty) {
+        // the bits tx0..tx1 of row ty, word by word
+        uint32_t bit = ty * t8x + tx0;
+        const uint32_t last = ty * t8x + tx1;
+        while (bit <= last) {
+            const uint32_t word = bit >> 5, first_in = bit & 31u;
+            const uint32_t end_in = (last >> 5) == word ? (last & 31u) : 31u;
+            const uint32_t m = (end_in == 31u ? 0xffffffffu : ((1u << (end_in + 1u)) - 1u)) & ~((1u << first_in) - 1u);
+            if (word < n_words && (out[word] & m) != m) atomicOr(&out[word], m);     // (most cells find their bits set already)
+            bit = (word + 1u) << 5;
+        }
+    }
+}
+
 // per-cell maxima of the density volume: cell (cx,cy,cz) of the mc_n^3 grid covers the voxels a
 // nearest-filter sample with pos in [c/mc_n, (c+1)/mc_n) can select, i.e. floor(pos*n) for those pos.
 __global__ __launch_bounds__(256) void volym_macrocell_kernel(const uint8_t* __restrict__ vol, uint8_t* __restrict__ mc_max,

@@ -84,7 +84,8 @@ __device__ __forceinline__ HullEdge load_hull_edge(const FrameParams& fp, uint32
     r.a = fp.hull[h][e][0]; r.b = fp.hull[h][e][1]; r.c = fp.hull[h][e][2]; r.valid = fp.hull[h][e][3] > 0.5f;
     return r;
 }
-__device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, const HullEdge& edge, uint32_t lane, float x0, float y0, float extent = 7.0f)
+__device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, const HullEdge& edge, uint32_t lane, float x0, float y0, float extent = 7.0f,
+                                                   bool masked_out = false)
 {
     const uint32_t k = lane & 3u;
     const float cx = (k & 1u) ? x0 + extent : x0, cy = (k & 2u) ? y0 + extent : y0;
@@ -98,10 +99,16 @@ __device__ __forceinline__ uint32_t classify_tile(const FrameParams& fp, const H
     const bool cube_ok = (fp.cull & CULL_CUBE_HULL) != 0u, obj_ok = (fp.cull & CULL_OBJ_HULL) != 0u;
     const bool out_cube = cube_ok && outside(static_cast<uint32_t>(mo));
     const bool in_cube = cube_ok && static_cast<uint32_t>(mi) == 0xffffffffu;
-    const bool out_obj = (fp.cull & CULL_NOTHING_DENSE) != 0u || (obj_ok && outside(static_cast<uint32_t>(mo >> 32)));
+    const bool out_obj = masked_out || (fp.cull & CULL_NOTHING_DENSE) != 0u || (obj_ok && outside(static_cast<uint32_t>(mo >> 32)));
     if (out_cube) return TILE_FILL_MISS;
     if (out_obj) return in_cube ? TILE_FILL_EMPTY : TILE_HIT_TEST;
     return TILE_MARCH;
+}
+// tile_mask bit of the 8x8 tile (t8x, t8y) (wave-uniform)
+__device__ __forceinline__ bool tile_mask_bit(const FrameParams& fp, uint32_t t8x, uint32_t t8y)
+{
+    const uint32_t bit = t8y * fp.mask_t8x + t8x;
+    return ((fp.tile_mask[bit >> 5] >> (bit & 31u)) & 1u) != 0u;
 }
 // WAVES: waves per workgroup.  16 (four per SIMD, a budget of 128 VGPRs) for the common instantiation, which fits; the
 // importance / continuous-rho instantiations need ~150 registers and run 12 waves (three per SIMD, 168 VGPRs) instead of
@@ -151,6 +158,10 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     const bool imp_rendering = (IMP || IR) && (flags & F_IMP_RENDERING) != 0u;
     const bool need_imp = imp_coloring || imp_rendering;
 
+    // keep the tile-mask buffer that this view does not read zeroed: the next view's volym_tile_mask_kernel ORs its bits into it
+    // (a few words per workgroup; whether it has happened never decides a pixel, only whether an empty tile is marched)
+    if (fp.tile_mask_spare)
+        for (uint32_t wrd = blockIdx.x * (WAVES * 64u) + threadIdx.x; wrd < fp.mask_words; wrd += gridDim.x * (WAVES * 64u)) fp.tile_mask_spare[wrd] = 0u;
     if (VOLYM_DEV_SWITCHES && (fp.dev & 16u)) return;                    // launch + dispatch only
     // A launch whose costs are captured also reports when it ran: behind the costs, the end time of every wave and the start
     // time of every workgroup (100 MHz counter).  The host evens out what the counted costs mispredict (raymarch.hip, trim_list).
@@ -242,7 +253,11 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         if (is_super) {
             const uint32_t lt = raw0 & 0x3fffffffu;
             const uint32_t tx16 = tx, ty16 = ty;
-            const uint32_t cls = culling ? classify_tile(fp, hull_edge, lane, static_cast<float>(tx16 * 16u), static_cast<float>(ty16 * 16u), 15.0f) : TILE_MARCH;
+            bool masked16 = false;
+            if (culling && (fp.cull & CULL_TILE_MASK))
+                masked16 = !(tile_mask_bit(fp, tx16 * 2u, ty16 * 2u) || tile_mask_bit(fp, tx16 * 2u + 1u, ty16 * 2u) ||
+                             tile_mask_bit(fp, tx16 * 2u, ty16 * 2u + 1u) || tile_mask_bit(fp, tx16 * 2u + 1u, ty16 * 2u + 1u));
+            const uint32_t cls = culling ? classify_tile(fp, hull_edge, lane, static_cast<float>(tx16 * 16u), static_cast<float>(ty16 * 16u), 15.0f, masked16) : TILE_MARCH;
             if (cls >= TILE_FILL_EMPTY) {
                 const uint32_t packed = cls == TILE_FILL_MISS ? 0xff000000u : 0u;
                 if (flags & F_RASTER) {
@@ -291,7 +306,8 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         uint32_t trace_ray_iters = 0;                                // TRACE: iterations this lane's ray was active in
         uint32_t tclass = TILE_MARCH;
         if (culling && !dp) {
-            tclass = classify_tile(fp, hull_edge, lane, static_cast<float>(tx * 16u + ((sub & 1u) << 3)), static_cast<float>(ty * 16u + ((sub >> 1) << 3)));
+            const bool masked8 = (fp.cull & CULL_TILE_MASK) != 0u && !tile_mask_bit(fp, tx * 2u + (sub & 1u), ty * 2u + (sub >> 1));
+            tclass = classify_tile(fp, hull_edge, lane, static_cast<float>(tx * 16u + ((sub & 1u) << 3)), static_cast<float>(ty * 16u + ((sub >> 1) << 3)), 7.0f, masked8);
             if (tclass >= TILE_FILL_EMPTY) {            // no ray of this tile can differ from the constant
                 const uint32_t packed = tclass == TILE_FILL_MISS ? 0xff000000u : 0u;     // (0,0,0,1) wgsl:239 / (0,0,0,0) wgsl:328
                 if (flags & F_RASTER) {
@@ -433,6 +449,8 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         // Shading happens at one point of an iteration: right after the byte gathers of the next samples were issued,
         // so that the latency of those gathers and the shading of the previous samples overlap (the long chains of
         // dependent samples are what a frame ends on).
+        // (a two-batch form -- the twelve gradient gathers of 128 queued samples in flight together -- was built and measured for the
+        // tiles that queue several batches per iteration: 32.7 us against 32.3 without it; removed)
         auto drain = [&]() __attribute__((always_inline)) { while (q_count >= 64u) flush(64u); };
 
         if (VOLYM_DEV_SWITCHES && (fp.dev & 256u)) active = false;          // timing experiment: set-up and store only
@@ -963,7 +981,13 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         // batches, replayed steps (counted, not timed: the work list must not depend on the weather)
         // a depth-parallel iteration takes 8 samples per ray where the classic loop takes 4: its iterations count double, so
         // that a quarter's number estimates what its tile would cost as one item (the host takes the maximum of the four)
-        entry_cost += dp ? tile_iters * 10u + tile_flushes * 2u + tile_trips / 7u : 5u + tile_iters * 5u + tile_flushes * 2u + tile_trips / 7u;
+#ifndef VOLYM_COST_FLUSH
+#define VOLYM_COST_FLUSH 2u
+#endif
+#ifndef VOLYM_COST_FLUSH_DP
+#define VOLYM_COST_FLUSH_DP 2u
+#endif
+        entry_cost += dp ? tile_iters * 10u + tile_flushes * VOLYM_COST_FLUSH_DP + tile_trips / 7u : 5u + tile_iters * 5u + tile_flushes * VOLYM_COST_FLUSH + tile_trips / 7u;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
