@@ -27,6 +27,9 @@ def main():
         ctx.set_transfer_function(scene.default_lut())
         ctx.set_option(_lib.OPT_WRITE_F32, 1)
         ctx.set_option(_lib.OPT_DEPTH_PARALLEL, 0)          # no split tiles: every tile is marched one lane per ray
+        for kv in os.environ.get("VOLYM_DEV_OPTS", "").split(","):        # e.g. VOLYM_DEV_OPTS=117=0 (no tile mask)
+            if "=" in kv:
+                ctx.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
         ctx.update(st.camera_uniforms(), st.parameter_uniforms())
         ctx.time_batch(3)
         ctx.settle()
