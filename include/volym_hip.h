@@ -64,7 +64,8 @@ enum {
     VOLYM_OPT_MACRO_CELLS = 3, /* macro cells per axis (power of two, 4..32; default 32)    */
     VOLYM_OPT_VOLUME_LAYOUT = 4, /* device layout of the NEXT volume / importance upload: -1 = by size (default: 4x4x4
                                     bricks above 64 MiB), 0 = linear, 1 = bricks.  Invisible at this boundary. */
-    VOLYM_OPT_CULLING = 5,     /* 0 = no exact culling (projected hulls, AABB clip) in kernel 2; default 1 */
+    VOLYM_OPT_CULLING = 5,     /* 0 = no exact culling (projected hulls, AABB clip, per-view tile mask of the occupied cells) in
+                                  kernel 2; default 1 */
     VOLYM_OPT_COST_FEEDBACK = 6, /* 0 = kernel 2 keeps its centre-first work list; default 1 (lists re-dealt from counted costs) */
     VOLYM_OPT_DEPTH_PARALLEL = 7, /* tile cost from which kernel 2 marches a tile as four depth-parallel quarter items:
                                     < 0 adaptive (-N = N/10 x a wave's fair share of the frame; -1 = default), 0 never, > 0 explicit */
