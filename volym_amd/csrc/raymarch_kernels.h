@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void volym_tile_mask_kernel(const uint8_t* __r
             const uint32_t word = bit >> 5, first_in = bit & 31u;
             const uint32_t end_in = (last >> 5) == word ? (last & 31u) : 31u;
             const uint32_t m = (end_in == 31u ? 0xffffffffu : ((1u << (end_in + 1u)) - 1u)) & ~((1u << first_in) - 1u);
-            if (word < n_words && (out[word] & m) != m) atomicOr(&out[word], m);     // (most cells find their bits set already)
+            if (word < n_words) atomicOr(&out[word], m);     // (no value comes back: nothing waits)
             bit = (word + 1u) << 5;
         }
     }
