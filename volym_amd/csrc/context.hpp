@@ -120,6 +120,7 @@ struct volym_ctx {
         uint64_t view_serial = 0;
         bool captured_has_dp = false;
         bool continuous = false;
+        bool plain = false;                      // table mode, no importance mode (the common instantiation)
         uint32_t max_grid = 0, waves = 16;
         int dp_min_cost = -1;
         uint32_t dp_share_pct = 60, fill_cost = 2;

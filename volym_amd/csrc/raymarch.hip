@@ -290,13 +290,30 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
     // measured optimum: 1.5x for the table mode, 1.2x for the continuous-rho modes (their classic loop speculates only two
     // samples deep, a depth-parallel item four)
     const uint64_t tenths = job.dp_min_cost < -1 ? static_cast<uint64_t>(-job.dp_min_cost) : (job.continuous ? 12u : 15u);
-    // ... but never below the cost of a tile whose one wave takes about as long as the shortest frame this kernel renders: when
-    // culling leaves little other work (the fair share shrinks), splitting more tiles only adds work, it does not shorten
-    // the tiles that are already as fast as they get (scripts/dp_sweep.py: the optimum stayed at ~96 units, with or without the
-    // tile mask, while the fair share went from 53 to 40)
-    const uint64_t floor_cost = (job.dp_min_cost == -1 && !job.continuous) ? job.dp_floor : 64u;
+    // ... with a floor for the frames that are bound by the time of their long tiles rather than by throughput.  When culling leaves
+    // little other work the fair share shrinks, the rule above splits twice as many tiles, and the frame gets slower (1080p
+    // bonsai with the tile mask: 35.7 us instead of 32.3): a split tile's quarters still take ~0.55-0.65 of the tile's own time, so
+    // below ~0.65 x the heaviest tiles splitting adds work and shortens nothing.  Measured optima: 104-114 units on the 1080p
+    // bonsai (heaviest tiles ~200); the teapot at 1024x768 wants the first rule alone at steps 0.003-0.005 (its frames are
+    // throughput-bound, 55-75 us; the 0.55 rule alone costs it 10-15 %) and at step 0.02 (27 us; no heavy tiles: an absolute
+    // floor alone costs it 20 %).  Hence the smaller of the two: an absolute 104 units (a tile of ~30 us), and 0.65 x the 4th
+    // heaviest tile (one freak tile does not move it).
+    uint64_t floor_cost = 64u;
+    if (job.dp_min_cost == -1 && job.plain) {                   // (look-ahead and continuous-rho iterations cost more per unit)
+        uint16_t top[4] = {0, 0, 0, 0};
+        for (uint32_t item : geometric) {
+            uint16_t k = item_cost[item];
+            for (int i = 0; i < 4; ++i) if (k > top[i]) std::swap(k, top[i]);
+        }
+        floor_cost = std::max<uint64_t>(64u, std::min<uint64_t>(job.dp_floor, static_cast<uint64_t>(top[3]) * 65u / 100u));
+    }
     const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(floor_cost, tenths * total_cost / (10u * resident_waves) + 16));
     const uint32_t dp_thr = job.dp_min_cost < 0 ? adaptive : static_cast<uint32_t>(job.dp_min_cost);
+#if VOLYM_DEV_SWITCHES
+    if (std::getenv("VOLYM_TRIM_LOG"))
+        std::fprintf(stderr, "deal: total cost %llu, fair share %llu, floor %llu, split threshold %u (moving %d measuring %d)\n", static_cast<unsigned long long>(total_cost),
+                     static_cast<unsigned long long>(total_cost / resident_waves), static_cast<unsigned long long>(floor_cost), dp_thr, moving ? 1 : 0, measuring ? 1 : 0);
+#endif
     const bool dp_ok = job.dp_min_cost != 0 && !measuring;
     std::vector<std::pair<uint32_t, uint32_t>> keyed;      // (cost share, entry)
     keyed.reserve(geometric.size() * 2);
@@ -1067,6 +1084,9 @@ static int ensure_frame_resources(volym_ctx* c)
         c->fp.cull |= CULL_TILE_MASK;
         c->fp.tile_mask_spare = c->d_tile_mask + static_cast<size_t>(c->mask_cur ^ 1) * c->tile_mask_words;
         c->mask_pending = false;
+        // costs measured before the mask existed describe tiles that are constant from here on: for the cost feedback this is a
+        // new view (a list dealt from the old costs would balance work that is no longer there: 33.2 instead of 32.3 us)
+        if (c->view_launches >= 1u) c->view_serial.fetch_add(1, std::memory_order_relaxed);
     }
     c->view_launches++;
     return VOLYM_OK;
@@ -1248,6 +1268,7 @@ static int launch_march(volym_ctx* c)
             job.view_serial = c->view_serial.load(std::memory_order_relaxed);
             job.captured_has_dp = wl.has_dp;
             job.continuous = (fp.flags & (F_LINEAR | F_GAUSSIAN)) != 0u;
+            job.plain = table && no_imp;                  // the common instantiation: the split threshold's floor was measured for it
             job.max_grid = max_grid(c);
             job.waves = waves;
             job.dp_min_cost = c->dp_min_cost;
