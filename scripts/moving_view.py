@@ -27,6 +27,9 @@ def main():
         ctx.set_volume(vol, dims, 0)
         ctx.set_importances(np.zeros(256 ** 3, np.uint8), dims)
         ctx.set_transfer_function(scene.default_lut())
+        for kv in os.environ.get("VOLYM_DEV_OPTS", "").split(","):        # DEV build, e.g. VOLYM_DEV_OPTS=117=0 (no tile mask)
+            if "=" in kv:
+                ctx.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
         for fb, inflight in [(1, n) for n in args.in_flight] + [(0, 0)]:
             ctx.set_option(_lib.OPT_COST_FEEDBACK, fb)
             for deg in args.degrees:

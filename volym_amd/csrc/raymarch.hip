@@ -1066,11 +1066,12 @@ static int ensure_frame_resources(volym_ctx* c)
         c->mask_pending = c->mask_wanted;
         c->view_launches = 0;
     }
-    // The tile mask costs a kernel per view (~5 us + the gap before the march).  A frame of 4 Mpixels and more saves several
-    // times that on its first frame already; a 1080p frame saves ~1 us per frame (it is bound by its longest tiles, not by
-    // the work the mask removes): there the mask is built when a view is rendered a second time, so that a moving camera
-    // never pays for it (turntable: 52 us per frame without, 62 with a mask per view).
-    if (c->mask_pending && (c->view_launches >= 1u || static_cast<uint64_t>(c->W) * c->H >= (4ull << 20) || c->mask_eager)) {
+    // The tile mask costs a kernel per view (~13 us: device-scope atomics) and changes which tiles are constant from view to view.
+    // It is built when a view is rendered a SECOND time: a standing view has it from its second frame on; a moving camera
+    // never pays for it -- and does not want it: the lists it runs were dealt for earlier views, and a 16x16 entry that was
+    // constant under that view's mask is four marched tiles on one wave under this one's (turntable at 3840x2160, 1 degree per
+    // frame: 130 us per frame without a mask per view, 164 with; at 1080p, 0.25 degrees: 52 and 62).
+    if (c->mask_pending && (c->view_launches >= 1u || c->mask_eager)) {
         ClipMatrix M;
         std::memcpy(M.m, c->mask_clip, sizeof M.m);
         // into the buffer the launches so far have kept zeroed; the launches from here on read it and zero the other one
