@@ -21,6 +21,7 @@
 #include "context.hpp"
 #include "raymarch_kernels.h"
 #include "raymarch_pq.h"
+#include "raymarch_pool.h"
 #include "blit.h"
 
 using namespace volym;
@@ -51,6 +52,13 @@ static void recompute_shard(volym_ctx* c)
 }
 
 static uint32_t max_grid(const volym_ctx* c) { return static_cast<uint32_t>(c->n_cus) * c->wgs_per_cu; }
+
+// Does a plain frame with these flags run the ray pool (variant 3, raymarch_pool.h)?  The common instantiation only: nearest
+// filter, no smoothing, opacity on, no importance mode; every other flag set runs variant 2.
+static bool frame_uses_pool(const volym_ctx* c, uint32_t flags)
+{
+    return c->kernel_variant == 3 && !(flags & (F_LINEAR | F_GAUSSIAN | F_IMP_COLORING | F_IMP_RENDERING)) && (flags & F_OPACITY) && c->n_order16 != 0u;
+}
 
 // ---- host-side table construction (EXACT arithmetic, same recipe as the device) --------------
 static void host_texel_linear(float u, int n, int& i0, int& i1, float& w)
@@ -636,6 +644,35 @@ static int rebuild_lists(volym_ctx* c)
         list_to_device_form(c, c->geometric, c->h_list_pinned);
         HIPCHK(c, hipMemcpy(c->d_list[0], c->h_list_pinned, c->geometric.size() * 2u * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    {
+        // variant 3: the 16x16 tiles of this shard, centre first (the orbit camera targets the volume centre, src/camera.rs:23:
+        // the long rays start first); inside a ring of 32 pixels a hash decides
+        std::vector<std::pair<uint32_t, uint32_t>> keyed;
+        keyed.reserve(c->n_local);
+        for (uint32_t lt = 0; lt < c->n_local; ++lt) {
+            const uint32_t tile = lt * c->world + c->rank;
+            const uint32_t tx = tile % c->tiles_x, ty = tile / c->tiles_x;
+            const int dx = std::abs(2 * static_cast<int>(tx * 16u) + 16 - static_cast<int>(c->W)), dy = std::abs(2 * static_cast<int>(ty * 16u) + 16 - static_cast<int>(c->H));
+            uint32_t h = lt * 0x9E3779B1u;
+            h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+            keyed.emplace_back((static_cast<uint32_t>(std::max(dx, dy)) / 64u) << 20 | (h & 0xfffffu), lt);
+        }
+        std::sort(keyed.begin(), keyed.end());
+        std::vector<uint2> order(keyed.size());
+        for (size_t i = 0; i < keyed.size(); ++i) {
+            const uint32_t lt = keyed[i].second, tile = lt * c->world + c->rank;
+            order[i] = make_uint2(lt, (tile % c->tiles_x) | ((tile / c->tiles_x) << 16));
+        }
+        if (order.size() > c->order16_capacity) {
+            if (c->d_order16) (void)hipFree(c->d_order16);
+            c->d_order16 = nullptr; c->order16_capacity = 0;
+            hipError_t e = hipMalloc(&c->d_order16, order.size() * sizeof(uint2));
+            if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("work list (16x16 tiles): ") + hipGetErrorString(e));
+            c->order16_capacity = order.size();
+        }
+        if (!order.empty()) HIPCHK(c, hipMemcpy(c->d_order16, order.data(), order.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        c->n_order16 = static_cast<uint32_t>(order.size());
+    }
     c->lists_ready = true;
     return VOLYM_OK;
 }
@@ -747,6 +784,9 @@ int volym_create(volym_ctx** out, uint32_t width, uint32_t height, int device_id
     }
     if ((e = hipMalloc(&c->d_pack_counters, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pack counters)");
     if ((e = hipMemset(c->d_pack_counters, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMemset(pack counters)");
+    if ((e = hipMalloc(&c->d_pool_sync, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pool sync)");
+    if ((e = hipMemset(c->d_pool_sync, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMemset(pool sync)");
+    if ((e = hipMalloc(&c->d_pool_dbg, static_cast<size_t>(c->n_cus) * 8u * PL_WAVES * 16u * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pool timeline)");
     for (int i = 0; i < volym_ctx::TABLE_RING; ++i) {
         if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_tables[i]), sizeof(FrameTables), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(tables)");
         if ((e = hipEventCreateWithFlags(&c->tables_ev[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -788,6 +828,7 @@ void volym_destroy(volym_ctx* c)
     (void)hipFree(c->d_shard_own); (void)hipFree(c->d_frame_own); (void)hipFree(c->d_f32); (void)hipFree(c->d_blit);
     (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_pack_counters); (void)hipFree(c->d_counters); (void)hipFree(c->d_aabb); (void)hipFree(c->d_tile_mask);
     (void)hipFree(c->d_list[0]); (void)hipFree(c->d_list[1]); (void)hipFree(c->d_cost);
+    (void)hipFree(c->d_order16); (void)hipFree(c->d_pool_sync); (void)hipFree(c->d_pool_dbg);
     if (c->h_list_pinned) (void)hipHostFree(c->h_list_pinned);
     if (c->h_cost_pinned) (void)hipHostFree(c->h_cost_pinned);
     for (int i = 0; i < volym_ctx::TABLE_RING; ++i) {
@@ -820,7 +861,7 @@ int volym_settle(volym_ctx* c)
     if (!c->fb_job.error.empty()) { const std::string m = c->fb_job.error; c->fb_job.error.clear(); return fail(c, VOLYM_E_HIP, m); }
     // ... and run the feedback to its fixed point for the current view: frames of this view (what volym_compute_pass
     // enqueues) until the list in use is final -- measuring list, deal, re-balancing rounds (raymarch.hip, "cost feedback")
-    if (c->have_frame && c->kernel_variant == 2 && c->feedback && !c->feedback_frozen && c->lists_ready) {
+    if (c->have_frame && c->kernel_variant >= 2 && !frame_uses_pool(c, c->fp.flags) && c->feedback && !c->feedback_frozen && c->lists_ready) {
         for (int round = 0; round < 12; ++round) {
             const WorkList& wl = c->lists[c->cur];
             if (wl.entries.empty() || (wl.view_serial == c->view_serial.load(std::memory_order_relaxed) && wl.final_for_view)) break;
@@ -840,7 +881,7 @@ int volym_set_option(volym_ctx* c, int key, int value)
     if (!c) return VOLYM_E_INVALID;
     switch (key) {
     case VOLYM_OPT_KERNEL:
-        if (value < 0 || value > 2) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_KERNEL: 0 (direct), 1 (macro-cell) or 2 (persistent + shading queue)");
+        if (value < 0 || value > 3) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_KERNEL: 0 (direct), 1 (macro-cell), 2 (persistent tiles + shading queue) or 3 (ray pool)");
         c->kernel_variant = value;
         return VOLYM_OK;
     case VOLYM_OPT_WRITE_F32:
@@ -1209,7 +1250,20 @@ static int launch_march(volym_ctx* c)
     }
     Counters* cnt = COUNT ? c->d_counters : nullptr;
     uint4* trace = TRACE ? c->d_trace : nullptr;
-    if (c->kernel_variant == 2) {
+    if (!COUNT && !TRACE && frame_uses_pool(c, fp.flags)) {
+        // the ray pool (raymarch_pool.h): the common instantiation; every other flag set runs variant 2 below
+        const uint32_t pgrid = std::max(1u, std::min(c->n_order16, max_grid(c)));
+        if (c->bricked)
+            hipLaunchKernelGGL((volym_raymarch_pool_kernel<true>), dim3(pgrid), dim3(PL_WAVES * 64), 0, c->stream, c->d_vol, c->d_tables, c->d_df, c->d_order16, c->n_order16,
+                               c->d_pool_sync, c->d_shard, c->d_frame, c->d_f32, c->pool_dbg ? c->d_pool_dbg : nullptr, fp);
+        else
+            hipLaunchKernelGGL((volym_raymarch_pool_kernel<false>), dim3(pgrid), dim3(PL_WAVES * 64), 0, c->stream, c->d_vol, c->d_tables, c->d_df, c->d_order16, c->n_order16,
+                               c->d_pool_sync, c->d_shard, c->d_frame, c->d_f32, c->pool_dbg ? c->d_pool_dbg : nullptr, fp);
+        HIPCHK(c, hipGetLastError());
+        c->pool_launched = true;
+        return VOLYM_OK;
+    }
+    if (c->kernel_variant >= 2) {
         const bool plain = !COUNT && !TRACE;
         if (plain) feedback_poll(c);                      // adopt a list the feedback thread has finished
         const WorkList& wl = c->lists[c->cur];
@@ -1333,12 +1387,26 @@ int volym_throttle(volym_ctx* c, uint32_t max_in_flight)
     return VOLYM_OK;
 }
 
+// The ray-pool kernel (variant 3) bounds every wait it contains and reports a wait that ran out (a bug, never an input) in
+// d_pool_sync[2]; the blocking calls look at it, so that a broken frame is an error and not a picture.  Stream is idle here.
+static int check_pool_error(volym_ctx* c)
+{
+    if (!c->pool_launched) return VOLYM_OK;
+    uint32_t bits = 0;
+    HIPCHK(c, hipMemcpy(&bits, c->d_pool_sync + 2, sizeof bits, hipMemcpyDeviceToHost));
+    if (bits != 0u) {
+        (void)hipMemset(c->d_pool_sync, 0, 4 * sizeof(uint32_t));
+        return fail(c, VOLYM_E_HIP, "ray-pool kernel gave up waiting (error bits " + std::to_string(bits) + "): the frame is incomplete");
+    }
+    return VOLYM_OK;
+}
+
 int volym_sync(volym_ctx* c)
 {
     if (!c) return VOLYM_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return VOLYM_OK;
+    return check_pool_error(c);
 }
 
 int volym_read_rgba8(volym_ctx* c, uint8_t* out)
@@ -1347,7 +1415,7 @@ int volym_read_rgba8(volym_ctx* c, uint8_t* out)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out, c->d_frame, static_cast<size_t>(c->W) * c->H * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return VOLYM_OK;
+    return check_pool_error(c);
 }
 
 int volym_read_rgba32f(volym_ctx* c, float* out)
@@ -1563,6 +1631,18 @@ int volym_time_passes(volym_ctx* c, uint32_t n, float* ms_each)
 #if VOLYM_DEV_SWITCHES
 // ---- development build only (make DEV=1): not declared in the public headers, not in the product library ------------
 // per-item costs (uint16) as the feedback thread last saw them; out needs 4 * n_local entries
+// development: per-wave timeline of the NEXT ray-pool launches (on != 0) / read the last one back (blocking)
+int volym_dev_pool_timeline(volym_ctx* c, int on, uint32_t* out, uint32_t max_words)
+{
+    if (!c) return VOLYM_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t words = std::min(max_words, static_cast<uint32_t>(max_grid(c)) * PL_WAVES * 16u);
+    if (out && words) HIPCHK(c, hipMemcpy(out, c->d_pool_dbg, static_cast<size_t>(words) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    c->pool_dbg = on != 0;
+    return static_cast<int>(words);
+}
+
 int volym_dev_read_costs(volym_ctx* c, uint16_t* out, uint32_t max_items)
 {
     if (!c || !out) return VOLYM_E_INVALID;
@@ -1610,7 +1690,7 @@ int volym_dev_wave_trace(volym_ctx* c, uint32_t* out, uint32_t max_records)
     const WorkList& wl = c->lists[c->cur];
     const uint32_t n_items = static_cast<uint32_t>(wl.entries.size());
     const uint32_t pgrid = wl.grid ? wl.grid : std::max(1u, std::min((n_items + PQ_WAVES - 1) / PQ_WAVES, max_grid(c)));
-    const uint32_t waves = c->kernel_variant == 2 ? pgrid * PQ_WAVES : (c->n_local + 64u * 8u) * 4u;   // PQ_WAVES >= every instantiation's WAVES
+    const uint32_t waves = c->kernel_variant >= 2 ? pgrid * PQ_WAVES : (c->n_local + 64u * 8u) * 4u;   // PQ_WAVES >= every instantiation's WAVES
     const uint32_t records = waves * 2u;
     if (max_records < records) return fail(c, VOLYM_E_INVALID, "volym_dev_wave_trace: buffer too small");
     HIPCHK(c, hipMalloc(&c->d_trace, static_cast<size_t>(records) * sizeof(uint4)));
