@@ -10,7 +10,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True) + glob.glob(root + "/pmc*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        short = "pq" if "pq_kernel" in name else ("v1" if "raymarch_kernel<1" in name else ("v0" if "raymarch_kernel<0" in name else None))
+        short = "pool" if "pool_kernel" in name else "pq" if "pq_kernel" in name else ("v1" if "raymarch_kernel<1" in name else ("v0" if "raymarch_kernel<0" in name else None))
         if short is None:
             continue
         if "<true, true" in name or "<false, true" in name or "<1, true" in name or "<0, true" in name:

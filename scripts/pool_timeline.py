@@ -30,39 +30,45 @@ with demo.GpuContext(W, H, 0) as ctx:
     print("plain: %.2f us/frame" % (1e3 * ctx.time_batch(200) / 200))
     L.volym_dev_pool_timeline(ctx.handle, 1, None, 0)
     ctx.time_batch(3)
-    n = 256 * 16 * 16
+    NW = int(os.environ.get("PL_WAVES", "12"))
+    n = 256 * NW * 24
     buf = np.zeros(n, np.uint32)
     got = L.volym_dev_pool_timeline(ctx.handle, 0, buf.ctypes.data_as(C.POINTER(C.c_uint32)), n)
-    r = buf[:got].reshape(-1, 16).astype(np.int64)
-r = r[r[:, 1] != 0]
-t0 = r[:, 0].min()
+    r = buf[:got].reshape(-1, 24).astype(np.int64)
+live = r[:, 1] != 0
+t0 = r[live, 0].min()
 start, end = (r[:, 0] - t0) / 100.0, (r[:, 1] - t0) / 100.0     # us
 print("waves %d ; kernel span %.1f us ; wave start p50 %.2f max %.2f ; end p10 %.1f p50 %.1f p90 %.1f max %.1f" %
-      (len(r), end.max(), np.median(start), start.max(), np.percentile(end, 10), np.median(end), np.percentile(end, 90), end.max()))
-names = ["refill", "setup", "A", "D"]
+      (live.sum(), end[live].max(), np.median(start[live]), start[live].max(), np.percentile(end[live], 10), np.median(end[live]), np.percentile(end[live], 90), end[live].max()))
+names = ["idle", "fill", "classify", "setup", "A", "D"]
 for i, nme in enumerate(names):
-    print("jobs %-6s total %6d per wave mean %.1f max %d ; time per wave mean %.2f us (%.2f us per job)" %
-          (nme, r[:, 2 + i].sum(), r[:, 2 + i].mean(), r[:, 2 + i].max(), r[:, 10 + i].mean() / 100.0, r[:, 10 + i].sum() / 100.0 / max(1, r[:, 2 + i].sum())))
-print("idle turns per wave mean %.1f max %d ; idle time per wave mean %.2f us" % (r[:, 6].mean(), r[:, 6].max(), r[:, 9].mean() / 100.0))
+    if i == 0:
+        print("idle turns per wave mean %.1f max %d ; idle time per wave mean %.2f us" % (r[live, 2].mean(), r[live, 2].max(), r[live, 12].mean() / 100.0))
+        continue
+    jobs, ticks = r[live, 6 + i], r[live, 12 + i]
+    print("jobs %-8s total %6d per wave mean %.1f max %d ; time per wave mean %.2f us (%.2f us per job)" %
+          (nme, jobs.sum(), jobs.mean(), jobs.max(), ticks.mean() / 100.0, ticks.sum() / 100.0 / max(1, jobs.sum())))
 print("rays per A visit %.1f ; per D visit %.1f ; scheduler turns per wave mean %.0f max %d" %
-      (r[:, 7].sum() / max(1, r[:, 4].sum()), r[:, 8].sum() / max(1, r[:, 5].sum()), r[:, 14].mean(), r[:, 14].max()))
-wg_end = end.reshape(-1, 16).max(axis=1) if len(end) % 16 == 0 else end
-print("workgroup end us: min %.1f p50 %.1f p90 %.1f max %.1f" % (wg_end.min(), np.median(wg_end), np.percentile(wg_end, 90), wg_end.max()))
-if len(r) % 16 == 0:
-    R = r.reshape(-1, 16, 16)
-    E = end.reshape(-1, 16)
-    order_wg = np.argsort(E.max(axis=1))
+      (r[live, 3].sum() / max(1, r[live, 10].sum()), r[live, 4].sum() / max(1, r[live, 11].sum()), r[live, 5].mean(), r[live, 5].max()))
+print("D visits by lanes per ray (1, 2, 4): %s ; rays in them: %s" % (r[live, 18:21].sum(axis=0).tolist(), r[live, 21:24].sum(axis=0).tolist()))
+if live.all() and len(r) % NW == 0:
+    R = r.reshape(-1, NW, 24)
+    E = end.reshape(-1, NW)
+    wg_end = E.max(axis=1)
+    print("workgroup end us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f" % (wg_end.min(), np.percentile(wg_end, 10), np.median(wg_end), np.percentile(wg_end, 90), wg_end.max()))
+    order_wg = np.argsort(wg_end)
     def show(w):
         x = R[w]
-        print("  wg %3d end %.1f : refills %d setups %d A %d D %d raysA %d raysD %d idle %d ; wave ends %s ; D per wave %s" %
-              (w, E[w].max(), x[:, 2].sum(), x[:, 3].sum(), x[:, 4].sum(), x[:, 5].sum(), x[:, 7].sum(), x[:, 8].sum(), x[:, 6].sum(),
-               np.round(np.sort(E[w]), 0).astype(int).tolist(), x[:, 5].tolist()))
+        print("  wg %3d end %.1f : fill %d classify %d setup %d A %d D %d raysA %d raysD %d idle %d ; busy us/wave %.1f ; wave ends %s" %
+              (w, wg_end[w], x[:, 7].sum(), x[:, 8].sum(), x[:, 9].sum(), x[:, 10].sum(), x[:, 11].sum(), x[:, 3].sum(), x[:, 4].sum(), x[:, 2].sum(),
+               x[:, 13:18].sum() / 100.0 / NW, np.round(np.sort(E[w]), 0).astype(int).tolist()))
     print("slowest workgroups:")
-    for w in order_wg[-4:]:
+    for w in order_wg[-3:]:
         show(w)
-    print("median workgroups:")
-    for w in order_wg[len(order_wg) // 2 - 1: len(order_wg) // 2 + 1]:
+    print("median / fastest workgroups:")
+    for w in (order_wg[len(order_wg) // 2], order_wg[0]):
         show(w)
-    setups = R[:, :, 3].sum(axis=1)
-    print("setups per workgroup: min %d p50 %d max %d ; corr(setups, end) %.2f ; corr(raysD, end) %.2f" %
-          (setups.min(), np.median(setups), setups.max(), np.corrcoef(setups, E.max(axis=1))[0, 1], np.corrcoef(R[:, :, 8].sum(axis=1), E.max(axis=1))[0, 1]))
+    raysD = R[:, :, 4].sum(axis=1)
+    busy_t = R[:, :, 13:18].sum(axis=(1, 2)) / 100.0 / NW
+    print("raysD per workgroup: min %d mean %.0f max %d (max/mean %.3f) ; busy us per wave by workgroup: min %.1f mean %.1f max %.1f ; corr(raysD, end) %.2f" %
+          (raysD.min(), raysD.mean(), raysD.max(), raysD.max() / max(1.0, raysD.mean()), busy_t.min(), busy_t.mean(), busy_t.max(), np.corrcoef(raysD, wg_end)[0, 1]))

@@ -14,7 +14,7 @@ from tests import common
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4   # per-channel float tolerance stated by BASELINE.json
-VARIANTS = (0, 1, 2)   # VOLYM_OPT_KERNEL: direct, macro-cell, persistent + shading queue (default)
+VARIANTS = (0, 1, 2, 3)   # VOLYM_OPT_KERNEL: direct, macro-cell, persistent tiles + shading queue (default), ray pool (the common flag set; others run 2)
 
 
 def _ctx(W, H):

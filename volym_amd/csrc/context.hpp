@@ -107,10 +107,7 @@ struct volym_ctx {
     std::vector<uint8_t> item_is_dp;            // hysteresis of the depth-parallel split
     std::atomic<uint64_t> view_serial{1};       // bumped by every volym_update that changes the uniforms (read by the feedback thread)
     bool lists_ready = false;
-    // ---- variant 3 (ray pool): centre-first list of this shard's 16x16 tiles {local tile, x | y << 16} and {frame ticket, workgroups done, error bits}
-    uint2* d_order16 = nullptr;
-    uint32_t n_order16 = 0;
-    size_t order16_capacity = 0;
+    // ---- variant 3 (ray pool): {-, -, error bits of the frames so far}
     uint32_t* d_pool_sync = nullptr;
     bool pool_launched = false;
     uint32_t* d_pool_dbg = nullptr;             // development timeline of variant 3 (volym_dev_pool_timeline)
@@ -172,7 +169,7 @@ struct volym_ctx {
     volym_parameter_uniforms par_copy;
 
     volym::FrameParams fp;
-    int kernel_variant = 3;
+    int kernel_variant = 2;
     bool write_f32 = false;
     uint32_t xcd_bands = 0;
     std::string err;

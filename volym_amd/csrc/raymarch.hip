@@ -57,7 +57,7 @@ static uint32_t max_grid(const volym_ctx* c) { return static_cast<uint32_t>(c->n
 // filter, no smoothing, opacity on, no importance mode; every other flag set runs variant 2.
 static bool frame_uses_pool(const volym_ctx* c, uint32_t flags)
 {
-    return c->kernel_variant == 3 && !(flags & (F_LINEAR | F_GAUSSIAN | F_IMP_COLORING | F_IMP_RENDERING)) && (flags & F_OPACITY) && c->n_order16 != 0u;
+    return c->kernel_variant == 3 && !(flags & (F_LINEAR | F_GAUSSIAN | F_IMP_COLORING | F_IMP_RENDERING)) && (flags & F_OPACITY);
 }
 
 // ---- host-side table construction (EXACT arithmetic, same recipe as the device) --------------
@@ -152,6 +152,9 @@ static void compute_culling(volym_ctx* c)
     FrameParams& fp = c->fp;
     fp.cull = 0;
     std::memset(fp.hull, 0, sizeof fp.hull);
+    // variant 3's lattice rectangle: the whole frame unless the hull of the occupied cells says less (below)
+    fp.rect[0] = 0; fp.rect[1] = 0;
+    fp.rect[2] = (c->W + PL_SBW - 1u) / PL_SBW * PL_SBW; fp.rect[3] = (c->H + PL_SBH - 1u) / PL_SBH * PL_SBH;
     c->hull_dirty = false;
     c->mask_wanted = false;
     if (!c->culling) return;
@@ -183,6 +186,7 @@ static void compute_culling(volym_ctx* c)
     clip(fp.eye[0], fp.eye[1], fp.eye[2], ce);
     const double scale = std::fabs(M[3]) + std::fabs(M[7]) + std::fabs(M[11]) + std::fabs(M[15]);
     if (!(std::fabs(ce[3]) <= 1e-4 * scale)) return;
+    double bb[4] = {0, 0, 0, 0};      // bounding rectangle of the last projected box
     auto project_box = [&](const double blo[3], const double bhi[3], float out[8][4]) -> bool {
         P2 pts[8];
         for (int k = 0; k < 8; ++k) {
@@ -192,12 +196,23 @@ static void compute_culling(volym_ctx* c)
             pts[k].x = (q[0] / q[3] + 1.0) * 0.5 * c->W;     // wgsl:221-229 inverted: pixel = (ndc + 1)/2 * W
             pts[k].y = (1.0 - q[1] / q[3]) * 0.5 * c->H;
             if (!std::isfinite(pts[k].x) || !std::isfinite(pts[k].y)) return false;
+            bb[0] = k ? std::min(bb[0], pts[k].x) : pts[k].x; bb[1] = k ? std::min(bb[1], pts[k].y) : pts[k].y;
+            bb[2] = k ? std::max(bb[2], pts[k].x) : pts[k].x; bb[3] = k ? std::max(bb[3], pts[k].y) : pts[k].y;
         }
         return hull_edges(pts, 8, out);
     };
     const double c0[3] = {0, 0, 0}, c1[3] = {1, 1, 1};
     if (project_box(c0, c1, fp.hull[0])) fp.cull |= CULL_CUBE_HULL;
-    if (!none && project_box(lo, hi, fp.hull[1])) fp.cull |= CULL_OBJ_HULL;
+    if (!none && project_box(lo, hi, fp.hull[1])) {
+        fp.cull |= CULL_OBJ_HULL;
+        // every pixel outside the hull by more than its 1.5 pixel margin is constant: so is every pixel outside the hull's bounding
+        // rectangle grown by 3 pixels, rounded outwards to whole superblocks
+        const double x0 = std::max(0.0, std::floor((bb[0] - 3.0) / PL_SBW) * PL_SBW), y0 = std::max(0.0, std::floor((bb[1] - 3.0) / PL_SBH) * PL_SBH);
+        const double x1 = std::min(static_cast<double>(fp.rect[2]), std::ceil((bb[2] + 3.0) / PL_SBW) * PL_SBW), y1 = std::min(static_cast<double>(fp.rect[3]), std::ceil((bb[3] + 3.0) / PL_SBH) * PL_SBH);
+        if (x1 > x0 && y1 > y0) { fp.rect[0] = static_cast<uint32_t>(x0); fp.rect[1] = static_cast<uint32_t>(y0); fp.rect[2] = static_cast<uint32_t>(x1); fp.rect[3] = static_cast<uint32_t>(y1); }
+        else { fp.rect[0] = fp.rect[1] = fp.rect[2] = fp.rect[3] = 0; }       // the object is off screen
+    }
+    if (none) { fp.rect[0] = fp.rect[1] = fp.rect[2] = fp.rect[3] = 0; }
     // the per-tile mask of the occupied cells' projections (volym_tile_mask_kernel): its cells lie inside the AABB whose
     // corners were all found in front of the eye, so their corners are too
     fp.mask_t8x = c->tiles_x * 2u;
@@ -644,35 +659,6 @@ static int rebuild_lists(volym_ctx* c)
         list_to_device_form(c, c->geometric, c->h_list_pinned);
         HIPCHK(c, hipMemcpy(c->d_list[0], c->h_list_pinned, c->geometric.size() * 2u * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    {
-        // variant 3: the 16x16 tiles of this shard, centre first (the orbit camera targets the volume centre, src/camera.rs:23:
-        // the long rays start first); inside a ring of 32 pixels a hash decides
-        std::vector<std::pair<uint32_t, uint32_t>> keyed;
-        keyed.reserve(c->n_local);
-        for (uint32_t lt = 0; lt < c->n_local; ++lt) {
-            const uint32_t tile = lt * c->world + c->rank;
-            const uint32_t tx = tile % c->tiles_x, ty = tile / c->tiles_x;
-            const int dx = std::abs(2 * static_cast<int>(tx * 16u) + 16 - static_cast<int>(c->W)), dy = std::abs(2 * static_cast<int>(ty * 16u) + 16 - static_cast<int>(c->H));
-            uint32_t h = lt * 0x9E3779B1u;
-            h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
-            keyed.emplace_back((static_cast<uint32_t>(std::max(dx, dy)) / 64u) << 20 | (h & 0xfffffu), lt);
-        }
-        std::sort(keyed.begin(), keyed.end());
-        std::vector<uint2> order(keyed.size());
-        for (size_t i = 0; i < keyed.size(); ++i) {
-            const uint32_t lt = keyed[i].second, tile = lt * c->world + c->rank;
-            order[i] = make_uint2(lt, (tile % c->tiles_x) | ((tile / c->tiles_x) << 16));
-        }
-        if (order.size() > c->order16_capacity) {
-            if (c->d_order16) (void)hipFree(c->d_order16);
-            c->d_order16 = nullptr; c->order16_capacity = 0;
-            hipError_t e = hipMalloc(&c->d_order16, order.size() * sizeof(uint2));
-            if (e != hipSuccess) return fail(c, VOLYM_E_NOMEM, std::string("work list (16x16 tiles): ") + hipGetErrorString(e));
-            c->order16_capacity = order.size();
-        }
-        if (!order.empty()) HIPCHK(c, hipMemcpy(c->d_order16, order.data(), order.size() * sizeof(uint2), hipMemcpyHostToDevice));
-        c->n_order16 = static_cast<uint32_t>(order.size());
-    }
     c->lists_ready = true;
     return VOLYM_OK;
 }
@@ -786,7 +772,7 @@ int volym_create(volym_ctx** out, uint32_t width, uint32_t height, int device_id
     if ((e = hipMemset(c->d_pack_counters, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMemset(pack counters)");
     if ((e = hipMalloc(&c->d_pool_sync, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pool sync)");
     if ((e = hipMemset(c->d_pool_sync, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMemset(pool sync)");
-    if ((e = hipMalloc(&c->d_pool_dbg, static_cast<size_t>(c->n_cus) * 8u * PL_WAVES * 16u * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pool timeline)");
+    if ((e = hipMalloc(&c->d_pool_dbg, static_cast<size_t>(c->n_cus) * 8u * PL_WAVES * 24u * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pool timeline)");
     for (int i = 0; i < volym_ctx::TABLE_RING; ++i) {
         if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_tables[i]), sizeof(FrameTables), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(tables)");
         if ((e = hipEventCreateWithFlags(&c->tables_ev[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -828,7 +814,7 @@ void volym_destroy(volym_ctx* c)
     (void)hipFree(c->d_shard_own); (void)hipFree(c->d_frame_own); (void)hipFree(c->d_f32); (void)hipFree(c->d_blit);
     (void)hipFree(c->d_gather_tmp); (void)hipFree(c->d_pack_counters); (void)hipFree(c->d_counters); (void)hipFree(c->d_aabb); (void)hipFree(c->d_tile_mask);
     (void)hipFree(c->d_list[0]); (void)hipFree(c->d_list[1]); (void)hipFree(c->d_cost);
-    (void)hipFree(c->d_order16); (void)hipFree(c->d_pool_sync); (void)hipFree(c->d_pool_dbg);
+    (void)hipFree(c->d_pool_sync); (void)hipFree(c->d_pool_dbg);
     if (c->h_list_pinned) (void)hipHostFree(c->h_list_pinned);
     if (c->h_cost_pinned) (void)hipHostFree(c->h_cost_pinned);
     for (int i = 0; i < volym_ctx::TABLE_RING; ++i) {
@@ -1252,13 +1238,14 @@ static int launch_march(volym_ctx* c)
     uint4* trace = TRACE ? c->d_trace : nullptr;
     if (!COUNT && !TRACE && frame_uses_pool(c, fp.flags)) {
         // the ray pool (raymarch_pool.h): the common instantiation; every other flag set runs variant 2 below
-        const uint32_t pgrid = std::max(1u, std::min(c->n_order16, max_grid(c)));
+        const uint32_t pgrid = std::min(256u, max_grid(c));         // (the lattice has 256 cells per superblock)
+        uint32_t* dbg = c->pool_dbg ? c->d_pool_dbg : nullptr;
         if (c->bricked)
-            hipLaunchKernelGGL((volym_raymarch_pool_kernel<true>), dim3(pgrid), dim3(PL_WAVES * 64), 0, c->stream, c->d_vol, c->d_tables, c->d_df, c->d_order16, c->n_order16,
-                               c->d_pool_sync, c->d_shard, c->d_frame, c->d_f32, c->pool_dbg ? c->d_pool_dbg : nullptr, fp);
+            hipLaunchKernelGGL((volym_raymarch_pool_kernel<true>), dim3(pgrid), dim3(PL_WAVES * 64), 0, c->stream, c->d_vol, c->d_tables, c->d_df, c->d_pool_sync, c->d_shard,
+                               c->d_frame, c->d_f32, dbg, fp);
         else
-            hipLaunchKernelGGL((volym_raymarch_pool_kernel<false>), dim3(pgrid), dim3(PL_WAVES * 64), 0, c->stream, c->d_vol, c->d_tables, c->d_df, c->d_order16, c->n_order16,
-                               c->d_pool_sync, c->d_shard, c->d_frame, c->d_f32, c->pool_dbg ? c->d_pool_dbg : nullptr, fp);
+            hipLaunchKernelGGL((volym_raymarch_pool_kernel<false>), dim3(pgrid), dim3(PL_WAVES * 64), 0, c->stream, c->d_vol, c->d_tables, c->d_df, c->d_pool_sync, c->d_shard,
+                               c->d_frame, c->d_f32, dbg, fp);
         HIPCHK(c, hipGetLastError());
         c->pool_launched = true;
         return VOLYM_OK;
@@ -1637,7 +1624,7 @@ int volym_dev_pool_timeline(volym_ctx* c, int on, uint32_t* out, uint32_t max_wo
     if (!c) return VOLYM_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const uint32_t words = std::min(max_words, static_cast<uint32_t>(max_grid(c)) * PL_WAVES * 16u);
+    const uint32_t words = std::min(max_words, static_cast<uint32_t>(max_grid(c)) * PL_WAVES * 24u);
     if (out && words) HIPCHK(c, hipMemcpy(out, c->d_pool_dbg, static_cast<size_t>(words) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     c->pool_dbg = on != 0;
     return static_cast<int>(words);

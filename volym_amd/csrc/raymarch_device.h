@@ -63,6 +63,8 @@ struct FrameParams {
                                  // meet anything dense
     uint32_t* tile_mask_spare;   // the mask buffer this view does not use: every launch zeroes it for the next view's mask kernel
     uint32_t mask_words;
+    uint32_t rect[4];            // variant 3: the screen rectangle {x0, y0, x1, y1} (pixels, whole 64x32 superblocks, x1/y1 may pass the frame) outside of
+                                 // which no ray can meet anything dense; x1 <= x0: no such pixel at all
 };
 
 #ifndef VOLYM_DEV_SWITCHES
