@@ -74,8 +74,19 @@ def main(seconds=None, seed=None):
                 ctx.update(*views[cur])
             elif r < 93:
                 ctx.set_option(_lib.OPT_REBALANCE_ROUNDS, int(rng.integers(0, 3)))
+            elif r < 94:
+                ctx.throttle(int(rng.integers(1, 9)))
             elif r < 95:
-                ctx.throttle(int(rng.integers(1, 4)))
+                if rng.integers(0, 2):
+                    # a shard change with frames (and possibly a cost capture) in flight, some frames of the shard, and back
+                    ctx.set_shard(int(rng.integers(0, 2)), int(rng.integers(2, 5)))
+                    for _ in range(int(rng.integers(1, 4))):
+                        ctx.compute_pass()
+                        frames += 1
+                    ctx.set_shard(0, 1)
+                else:
+                    ctx.set_option(_lib.OPT_KERNEL, int(rng.choice([2, 3])))     # tiles + shading queue / ray pool: the same pixels
+                ctx.update(*views[cur])
             else:
                 ctx.compute_pass()
                 frames += 1

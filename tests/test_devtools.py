@@ -28,3 +28,12 @@ def test_seg_nrrd_roundtrip(tmp_path, volym_lib):
     segs[0]["importance"] = 255
     imp = scene.map_segments_to_importance(labels, scene.load_segments(segs))
     assert set(np.unique(imp)) == {0, 255} and np.array_equal(imp == 255, labels == 2)
+
+
+def test_segment_index_above_255_is_refused():
+    """volym_devtools/src/main.rs:50 parses the index as a u8 and panics above 255; a silent wrap would overwrite Segment0"""
+    import pytest
+    from volym_amd import devtools
+    lines = [b"Segment0_Name:=A", b"Segment0_ID:=a", b"Segment0_LabelValue:=1", b"Segment256_Name:=B"]
+    with pytest.raises(ValueError):
+        devtools.read_segments(lines)

@@ -63,6 +63,54 @@ def test_virtual_ranks_native_loop(volym_lib, world):
 
 
 @pytest.mark.gpu
+def test_packed_overflow_is_an_error_and_prepare_recovers(volym_lib):
+    """Slots sized for a view in which the object is small overflow when the camera moves in: the run fails (a frame with
+    transparent tiles in it is not a frame), and preparing again for the new view gives correct frames with the flag clear."""
+    from volym_amd import _lib, mgpu
+    W, H = 310, 170
+    dims, vol, imp, lut, state = _scene(W, H)
+    with mgpu.MultiGpu(W, H, devices=[0, 0], transport=mgpu.COPY) as mg:
+        mg.set_volume(vol, dims, 0)
+        mg.set_importances(imp, dims)
+        mg.set_transfer_function(lut)
+        state.process_scroll(-40.0)                      # zoom out: few tiles hold anything
+        state.update()
+        mg.update(state.camera_uniforms(), state.parameter_uniforms())
+        mg.prepare(0)
+        assert mg.run(3, use_graph=False)["overflowed"] == 0
+        state.process_scroll(40.0)                       # back in: more tiles than the slots sized above
+        state.update()
+        mg.update(state.camera_uniforms(), state.parameter_uniforms())
+        with pytest.raises(_lib.VolymError) as e:
+            mg.run(3, use_graph=False)
+        assert "overflowed" in str(e.value)
+        mg.prepare(0)                                    # the documented recovery
+        t = mg.run(3, use_graph=False)
+        assert t["overflowed"] == 0
+        assert np.array_equal(mg.read_rgba8(), _solo(W, H, dims, vol, imp, lut, state))
+
+
+@pytest.mark.gpu
+def test_throttle_accepts_its_whole_range(volym_lib):
+    """volym_throttle(8) must wait for the mark made 8 calls ago, not for the frame just enqueued (ring of 9 marks)."""
+    from volym_amd import demo
+    W, H = 160, 96
+    dims, vol, imp, lut, state = _scene(W, H)
+    with demo.GpuContext(W, H, 0) as c:
+        c.set_volume(vol, dims, 0)
+        c.set_importances(imp, dims)
+        c.set_transfer_function(lut)
+        c.update(state.camera_uniforms(), state.parameter_uniforms())
+        for depth in (1, 3, 8):
+            for _ in range(20):
+                c.compute_pass()
+                c.throttle(depth)
+        with pytest.raises(Exception):
+            c.throttle(9)
+        c.sync()
+
+
+@pytest.mark.gpu
 def test_single_rank_rccl_and_graph(volym_lib):
     """One process per device, world = 1: the create_rank path (no peer, so no RCCL traffic) and the graph replay of a
     static view give the solo frame."""

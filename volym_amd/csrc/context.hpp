@@ -140,7 +140,7 @@ struct volym_ctx {
         std::string error;                       // worker -> caller
     } fb_job;
 
-    static constexpr uint32_t THROTTLE_RING = 8;
+    static constexpr uint32_t THROTTLE_RING = 9;          // one more than the deepest wait volym_throttle accepts (8)
     hipEvent_t throttle_ev[THROTTLE_RING] = {};
     uint32_t throttle_head = 0;
 

@@ -964,6 +964,11 @@ int volym_set_shard(volym_ctx* c, uint32_t rank, uint32_t world)
 {
     if (!c) return VOLYM_E_INVALID;
     if (world == 0 || rank >= world || world > 4096) return fail(c, VOLYM_E_INVALID, "volym_set_shard: need rank < world <= 4096");
+    // the feedback thread reads rank / world / n_local while it deals a list: let a job in flight finish (and the frames that
+    // read the current lists) before any of them changes
+    feedback_quiesce(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->rank = rank; c->world = world;
     recompute_shard(c);
     return rebuild_lists(c);
@@ -1361,8 +1366,11 @@ int volym_compute_pass(volym_ctx* c)
 int volym_throttle(volym_ctx* c, uint32_t max_in_flight)
 {
     if (!c) return VOLYM_E_INVALID;
-    if (max_in_flight == 0 || max_in_flight > volym_ctx::THROTTLE_RING) return fail(c, VOLYM_E_INVALID, "volym_throttle: max_in_flight must be 1..8");
+    if (max_in_flight == 0 || max_in_flight >= volym_ctx::THROTTLE_RING) return fail(c, VOLYM_E_INVALID, "volym_throttle: max_in_flight must be 1..8");
     HIPCHK(c, hipSetDevice(c->device));
+    // The ring holds one slot more than the deepest wait (9 slots, max_in_flight <= 8): the mark made max_in_flight calls ago
+    // is never the slot recorded by this call, and the slot recorded here was last recorded 9 calls ago -- an earlier call has
+    // already waited for a later mark than that one (marks complete in stream order).
     const uint32_t slot = c->throttle_head % volym_ctx::THROTTLE_RING;
     if (!c->throttle_ev[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->throttle_ev[slot], hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->throttle_ev[slot], c->stream));

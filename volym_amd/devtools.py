@@ -25,20 +25,28 @@ def split_nrrd(data):
     return data.replace(b"\r\n", b"\n").split(b"\n"), b""
 
 
+def _segment_index(m):
+    """Segment<N>: the reference parses N as a u8 and panics above 255 (volym_devtools/src/main.rs:50)"""
+    idx = int(m.group(1))
+    if idx > 255:
+        raise ValueError("segment index %d does not fit a u8 (volym_devtools/src/main.rs:50 refuses it)" % idx)
+    return idx
+
+
 def read_segments(header_lines):
     names, ids, labels = {}, {}, {}
     for line in header_lines:
         m = _NAME.search(line)
         if m:
-            names[int(m.group(1)) & 255] = m.group(2).decode("utf-8", "replace")
+            names[_segment_index(m)] = m.group(2).decode("utf-8", "replace")
             continue
         m = _ID.search(line)
         if m:
-            ids[int(m.group(1)) & 255] = m.group(2).decode("utf-8", "replace")
+            ids[_segment_index(m)] = m.group(2).decode("utf-8", "replace")
             continue
         m = _LABEL.search(line)
         if m:
-            labels[int(m.group(1)) & 255] = int(m.group(2))
+            labels[_segment_index(m)] = int(m.group(2))
     segs = []
     for index in sorted(names):
         if index not in ids or index not in labels:
