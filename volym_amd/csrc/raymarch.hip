@@ -879,8 +879,8 @@ int volym_set_option(volym_ctx* c, int key, int value)
         }
         return VOLYM_OK;
     case VOLYM_OPT_MACRO_CELLS:
-        if (value < 4 || value > 32 || (value & (value - 1)) != 0)
-            return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_MACRO_CELLS: power of two in 4..32");
+        if (value < 4 || value > 64 || (value & (value - 1)) != 0)
+            return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_MACRO_CELLS: power of two in 4..64");
         c->mc_n = static_cast<uint32_t>(value);
         if (c->have_vol) { int rc = build_macro_cells(c); if (rc != VOLYM_OK) return rc; }
         return forget_costs(c);
@@ -1110,8 +1110,15 @@ static int ensure_frame_resources(volym_ctx* c)
         c->mask_cur ^= 1;
         uint32_t* cur = c->d_tile_mask + static_cast<size_t>(c->mask_cur) * c->tile_mask_words;
         const uint32_t cells = c->mc_n * c->mc_n * c->mc_n;
-        hipLaunchKernelGGL(volym_tile_mask_kernel, dim3((cells + 255u) / 256u), dim3(256), 0, c->stream, c->d_mc, c->mc_n, c->thr_byte_cull, M, c->mask_margin,
-                           c->W, c->H, c->tiles_x * 2u, c->tile_mask_words, cur);
+        if (static_cast<size_t>(c->tile_mask_words) * sizeof(uint32_t) <= 48u * 1024u) {
+            // the mask fits LDS: aggregated per block of cells, only the words that are not zero travel
+            const uint32_t nb = (c->mc_n + 7u) / 8u;
+            hipLaunchKernelGGL(volym_tile_mask_lds_kernel, dim3(nb * nb * ((c->mc_n + 3u) / 4u)), dim3(256), c->tile_mask_words * sizeof(uint32_t), c->stream, c->d_mc, c->mc_n,
+                               c->thr_byte_cull, M, c->mask_margin, c->W, c->H, c->tiles_x * 2u, c->tile_mask_words, cur);
+        } else {
+            hipLaunchKernelGGL(volym_tile_mask_kernel, dim3((cells + 255u) / 256u), dim3(256), 0, c->stream, c->d_mc, c->mc_n, c->thr_byte_cull, M, c->mask_margin,
+                               c->W, c->H, c->tiles_x * 2u, c->tile_mask_words, cur);
+        }
         HIPCHK(c, hipGetLastError());
         c->fp.tile_mask = cur;
         c->fp.cull |= CULL_TILE_MASK;

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
         if (!m.table_mode) s_lut[i] = tables->lut_f[i];
         if (flags & F_IMP_COLORING) s_ic_alpha[i] = tables->ic_alpha[i];
         if (use_df) {
-            const uint32_t n16 = (fp.mc_n * fp.mc_n * fp.mc_n / 2u + 15u) / 16u;   // 16-byte pieces
+            const uint32_t n16 = fp.mc_n <= 32u ? (fp.mc_n * fp.mc_n * fp.mc_n / 2u + 15u) / 16u : 0u;   // 16-byte pieces (a finer grid stays in global memory)
             const uint4* src = reinterpret_cast<const uint4*>(df4);
             uint4* dst = reinterpret_cast<uint4*>(s_df);
             for (uint32_t k = i; k < n16; k += 256u) dst[k] = src[k];
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
                     uint32_t D = 0;
                     if (static_cast<uint32_t>(cx | cy | cz) < fp.mc_n) {
                         const uint32_t ci = static_cast<uint32_t>(cx) + fp.mc_n * (static_cast<uint32_t>(cy) + fp.mc_n * static_cast<uint32_t>(cz));
-                        D = (static_cast<uint32_t>(s_df[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
+                        D = (static_cast<uint32_t>(fp.mc_n <= 32u ? s_df[ci >> 1] : df4[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
                     }
                     if (D != 0u) {
                         // box of empty cells [c-R, c+R+1]/mc_n shrunk by eps on every face, R = D-1
@@ -295,70 +295,104 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
 // hold a voxel >= thr_byte; 0 for such cells.  Cells outside the grid count as empty.  Output packed
 // two cells per byte (low nibble = even cell).  Also emits the AABB of the occupied cells.
 //
-// One workgroup, bit-parallel: thread r owns the row (y, z) = (r % n, r / n) as one 32-bit word (bit x).
-// mask_0 = occupied, mask_k = mask_{k-1} dilated by one cell along x, y and z (a 3x3x3 box); the masks
-// are nested, so D(c) = #{k in 0..14 : c not in mask_k}, accumulated in four bit planes.
+// One workgroup, bit-parallel: a row (y, z) of the grid is one 64-bit word (bit x), thread r owns the rows r, r + 1024, ...
+// (n <= 64: at most four).  mask_0 = occupied, mask_k = mask_{k-1} dilated by one cell along x, y and z (a 3x3x3 box); the
+// masks are nested, so D(c) = #{k in 0..14 : c not in mask_k}, accumulated in four bit planes.
+constexpr uint32_t VOLYM_DF_MAX_N = 64;
 __global__ __launch_bounds__(1024) void volym_distance_field_kernel(const uint8_t* __restrict__ mc_max, uint8_t* __restrict__ df4,
                                                                     int* __restrict__ aabb, uint32_t mc_n, uint32_t thr_byte)
 {
-    __shared__ uint32_t rows[32 * 32];
-    __shared__ uint32_t tmp[32 * 32];
+    typedef unsigned long long u64;
+    constexpr int RPT = (VOLYM_DF_MAX_N * VOLYM_DF_MAX_N) / 1024;     // rows per thread
+    __shared__ u64 rows[VOLYM_DF_MAX_N * VOLYM_DF_MAX_N];
+    __shared__ u64 tmp[VOLYM_DF_MAX_N * VOLYM_DF_MAX_N];
     __shared__ int s_box[6];
-    const uint32_t r = threadIdx.x, n = mc_n;
-    const bool live = r < n * n;
-    const uint32_t y = live ? r % n : 0u, z = live ? r / n : 0u;
-    if (r < 6u) s_box[r] = (r < 3u) ? static_cast<int>(n) : -1;
-    uint32_t m = 0;
-    if (live)
-        for (uint32_t x = 0; x < n; ++x)
-            if (mc_max[x + n * (y + n * z)] >= thr_byte) m |= 1u << x;
-    __syncthreads();
-    if (live && m) {
-        atomicMin(&s_box[0], __builtin_ctz(m));
-        atomicMax(&s_box[3], 31 - __builtin_clz(m));
-        atomicMin(&s_box[1], static_cast<int>(y)); atomicMax(&s_box[4], static_cast<int>(y));
-        atomicMin(&s_box[2], static_cast<int>(z)); atomicMax(&s_box[5], static_cast<int>(z));
+    const uint32_t n = mc_n, n_rows = n * n;
+    if (threadIdx.x < 6u) s_box[threadIdx.x] = (threadIdx.x < 3u) ? static_cast<int>(n) : -1;
+    u64 m[RPT], p0[RPT], p1[RPT], p2[RPT], p3[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const uint32_t r = threadIdx.x + 1024u * i;
+        m[i] = 0; p0[i] = p1[i] = p2[i] = p3[i] = 0;
+        if (r < n_rows) {
+            const uint32_t y = r % n, z = r / n;
+            for (uint32_t x = 0; x < n; ++x)
+                if (mc_max[x + n * (y + n * z)] >= thr_byte) m[i] |= 1ull << x;
+        }
     }
-    const uint32_t row_mask = n >= 32u ? 0xffffffffu : ((1u << n) - 1u);
-    uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;             // bit planes of the per-cell count
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const uint32_t r = threadIdx.x + 1024u * i;
+        if (r < n_rows && m[i]) {
+            const uint32_t y = r % n, z = r / n;
+            atomicMin(&s_box[0], __builtin_ctzll(m[i]));
+            atomicMax(&s_box[3], 63 - __builtin_clzll(m[i]));
+            atomicMin(&s_box[1], static_cast<int>(y)); atomicMax(&s_box[4], static_cast<int>(y));
+            atomicMin(&s_box[2], static_cast<int>(z)); atomicMax(&s_box[5], static_cast<int>(z));
+        }
+    }
+    const u64 row_mask = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
     for (int k = 0; k < 15; ++k) {
         // count += !mask_k  (bit-sliced ripple add of a one-bit addend)
-        uint32_t carry = ~m & row_mask;
-        uint32_t t0 = p0 & carry; p0 ^= carry; carry = t0;
-        t0 = p1 & carry; p1 ^= carry; carry = t0;
-        t0 = p2 & carry; p2 ^= carry; carry = t0;
-        p3 ^= carry;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            u64 carry = ~m[i] & row_mask;
+            u64 t0 = p0[i] & carry; p0[i] ^= carry; carry = t0;
+            t0 = p1[i] & carry; p1[i] ^= carry; carry = t0;
+            t0 = p2[i] & carry; p2[i] ^= carry; carry = t0;
+            p3[i] ^= carry;
+        }
         if (k == 14) break;
         // dilate: x in-register, then y and z through LDS
-        m = (m | (m << 1) | (m >> 1)) & row_mask;
-        if (live) rows[r] = m;
-        __syncthreads();
-        if (live) {
-            uint32_t v = m;
-            if (y > 0u) v |= rows[r - 1u];
-            if (y + 1u < n) v |= rows[r + 1u];
-            tmp[r] = v;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const uint32_t r = threadIdx.x + 1024u * i;
+            m[i] = (m[i] | (m[i] << 1) | (m[i] >> 1)) & row_mask;
+            if (r < n_rows) rows[r] = m[i];
         }
         __syncthreads();
-        if (live) {
-            uint32_t v = tmp[r];
-            if (z > 0u) v |= tmp[r - n];
-            if (z + 1u < n) v |= tmp[r + n];
-            m = v;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const uint32_t r = threadIdx.x + 1024u * i;
+            if (r < n_rows) {
+                const uint32_t y = r % n;
+                u64 v = m[i];
+                if (y > 0u) v |= rows[r - 1u];
+                if (y + 1u < n) v |= rows[r + 1u];
+                tmp[r] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const uint32_t r = threadIdx.x + 1024u * i;
+            if (r < n_rows) {
+                const uint32_t z = r / n;
+                u64 v = tmp[r];
+                if (z > 0u) v |= tmp[r - n];
+                if (z + 1u < n) v |= tmp[r + n];
+                m[i] = v;
+            }
         }
         __syncthreads();
     }
-    if (live) {
-        uint8_t* out = df4 + (static_cast<size_t>(n) * (y + n * z)) / 2u;
-        for (uint32_t x = 0; x < n; x += 2u) {
-            const uint32_t lo = ((p0 >> x) & 1u) | (((p1 >> x) & 1u) << 1) | (((p2 >> x) & 1u) << 2) | (((p3 >> x) & 1u) << 3);
-            const uint32_t x1 = x + 1u;
-            const uint32_t hi = ((p0 >> x1) & 1u) | (((p1 >> x1) & 1u) << 1) | (((p2 >> x1) & 1u) << 2) | (((p3 >> x1) & 1u) << 3);
-            out[x / 2u] = static_cast<uint8_t>(lo | (hi << 4));
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const uint32_t r = threadIdx.x + 1024u * i;
+        if (r < n_rows) {
+            const uint32_t y = r % n, z = r / n;
+            uint8_t* out = df4 + (static_cast<size_t>(n) * (y + n * z)) / 2u;
+            for (uint32_t x = 0; x < n; x += 2u) {
+                const uint32_t lo = static_cast<uint32_t>((p0[i] >> x) & 1ull) | (static_cast<uint32_t>((p1[i] >> x) & 1ull) << 1) | (static_cast<uint32_t>((p2[i] >> x) & 1ull) << 2) | (static_cast<uint32_t>((p3[i] >> x) & 1ull) << 3);
+                const uint32_t x1 = x + 1u;
+                const uint32_t hi = static_cast<uint32_t>((p0[i] >> x1) & 1ull) | (static_cast<uint32_t>((p1[i] >> x1) & 1ull) << 1) | (static_cast<uint32_t>((p2[i] >> x1) & 1ull) << 2) | (static_cast<uint32_t>((p3[i] >> x1) & 1ull) << 3);
+                out[x / 2u] = static_cast<uint8_t>(lo | (hi << 4));
+            }
         }
     }
     __syncthreads();
-    if (r < 6u) aabb[r] = s_box[r];
+    if (threadIdx.x < 6u) aabb[threadIdx.x] = s_box[threadIdx.x];
 }
 
 // Which 8x8 pixel tiles can see anything dense?  Every macro cell that may hold a voxel >= thr_byte (the criterion of the
@@ -420,6 +454,72 @@ __global__ __launch_bounds__(256) void volym_tile_mask_kernel(const uint8_t* __r
             if (word < n_words) atomicOr(&out[word], m);     // (no value comes back: nothing waits)
             bit = (word + 1u) << 5;
         }
+    }
+}
+
+// The same mask, aggregated in LDS first: one workgroup per block of 8 x 8 x 4 macro cells (a compact piece of the volume: its
+// cells project onto neighbouring tiles), the bits ORed into a copy of the mask in LDS, and only the words that are not zero go
+// to global memory -- a few thousand device-scope atomics per view instead of one per (cell, tile row, word): ~13 us -> ~3 us
+// at 1920 x 1080.  Same rectangles, same bits.  n_words * 4 bytes of dynamic LDS (the caller falls back to the kernel above
+// for frames whose mask does not fit).
+__global__ __launch_bounds__(256) void volym_tile_mask_lds_kernel(const uint8_t* __restrict__ mc_max, uint32_t mc_n, uint32_t thr_byte, ClipMatrix M,
+                                                                  float margin, uint32_t W, uint32_t H, uint32_t t8x, uint32_t n_words,
+                                                                  uint32_t* __restrict__ out)
+{
+    extern __shared__ uint32_t s_mask[];
+    for (uint32_t i = threadIdx.x; i < n_words; i += 256u) s_mask[i] = 0u;
+    __syncthreads();
+    // block -> cell: blocks of 8 x 8 x 4 cells, x fastest
+    const uint32_t nbx = (mc_n + 7u) / 8u, nby = (mc_n + 7u) / 8u;
+    const uint32_t bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, bz = blockIdx.x / (nbx * nby);
+    const uint32_t cx = bx * 8u + (threadIdx.x & 7u), cy = by * 8u + ((threadIdx.x >> 3) & 7u), cz = bz * 4u + (threadIdx.x >> 6);
+    bool all_bits = false;
+    if (cx < mc_n && cy < mc_n && cz < mc_n && mc_max[cx + mc_n * (cy + mc_n * cz)] >= thr_byte) {
+        const float inv = 1.0f / static_cast<float>(mc_n);
+        const float fw = static_cast<float>(W), fh = static_cast<float>(H);
+        const float lo[3] = {static_cast<float>(cx) * inv - margin, static_cast<float>(cy) * inv - margin, static_cast<float>(cz) * inv - margin};
+        const float hi[3] = {static_cast<float>(cx + 1u) * inv + margin, static_cast<float>(cy + 1u) * inv + margin, static_cast<float>(cz + 1u) * inv + margin};
+        float px0 = 3.0e38f, px1 = -3.0e38f, py0 = 3.0e38f, py1 = -3.0e38f;
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float x = (k & 1) ? hi[0] : lo[0], y = (k & 2) ? hi[1] : lo[1], z = (k & 4) ? hi[2] : lo[2];
+            const float qx = M.m[0] * x + M.m[4] * y + M.m[8] * z + M.m[12];
+            const float qy = M.m[1] * x + M.m[5] * y + M.m[9] * z + M.m[13];
+            const float qw = M.m[3] * x + M.m[7] * y + M.m[11] * z + M.m[15];
+            if (!(qw > 0.0f)) bad = true;
+            const float iw = 1.0f / qw;
+            const float sx = (qx * iw + 1.0f) * 0.5f * fw, sy = (1.0f - qy * iw) * 0.5f * fh;
+            if (!(sx == sx) || !(sy == sy)) bad = true;
+            px0 = fminf(px0, sx); px1 = fmaxf(px1, sx); py0 = fminf(py0, sy); py1 = fmaxf(py1, sy);
+        }
+        if (bad) {
+            all_bits = true;                         // cannot happen under CULL_OBJ_HULL; be safe: everything is marched
+        } else {
+            const float gx = 1.5f + 1.0e-5f * fw, gy = 1.5f + 1.0e-5f * fh;
+            const float fx0 = fmaxf(ceilf(px0 - gx), 0.0f), fx1 = fminf(floorf(px1 + gx), fw - 1.0f);
+            const float fy0 = fmaxf(ceilf(py0 - gy), 0.0f), fy1 = fminf(floorf(py1 + gy), fh - 1.0f);
+            if (fx0 <= fx1 && fy0 <= fy1) {
+                const uint32_t tx0 = static_cast<uint32_t>(fx0) >> 3, tx1 = static_cast<uint32_t>(fx1) >> 3;
+                const uint32_t ty0 = static_cast<uint32_t>(fy0) >> 3, ty1 = static_cast<uint32_t>(fy1) >> 3;
+                for (uint32_t ty = ty0; ty <= ty1; ++ty) {
+                    uint32_t bit = ty * t8x + tx0;
+                    const uint32_t last = ty * t8x + tx1;
+                    while (bit <= last) {
+                        const uint32_t word = bit >> 5, first_in = bit & 31u;
+                        const uint32_t end_in = (last >> 5) == word ? (last & 31u) : 31u;
+                        const uint32_t m = (end_in == 31u ? 0xffffffffu : ((1u << (end_in + 1u)) - 1u)) & ~((1u << first_in) - 1u);
+                        if (word < n_words) atomicOr(&s_mask[word], m);
+                        bit = (word + 1u) << 5;
+                    }
+                }
+            }
+        }
+    }
+    const bool any_all = __syncthreads_or(all_bits ? 1 : 0) != 0;
+    for (uint32_t i = threadIdx.x; i < n_words; i += 256u) {
+        const uint32_t v = any_all ? 0xffffffffu : s_mask[i];
+        if (v) atomicOr(&out[i], v);
     }
 }
 
