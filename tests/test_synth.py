@@ -19,6 +19,14 @@ def test_bonsai_hashes_and_density():
     assert np.all(v[l == 0] <= 7) and np.all(v[l == 4] == 230)
 
 
+def test_ball_and_vessels_hashes():
+    """the two extra scenes of the scheduling rows (scripts/scene_rows.py): one long dense run per ray / sparse thin tubes"""
+    assert synth.sha256(synth.synth_ball(64)) == "2a7d0d413dc232f34f9535c8d91d4afc42902f9e55b9f43043f796e87e371f36"
+    v = synth.synth_vessels(64)
+    assert synth.sha256(v) == "d79f1153b5a134a9b86aea78f571f1879e1e2e4a3fb0d2ebc1f821b8df7b1965"
+    assert 0.02 < float((v >= 39).mean()) < 0.10
+
+
 def test_bonsai256_and_teapot_hashes():
     v = synth.synth_bonsai(256)
     assert synth.sha256(v) == "e0be5753326650e825c59a8f0fc756aac1bf2ee1d5e7088bcccda74e2f361718"

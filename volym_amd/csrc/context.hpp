@@ -133,7 +133,7 @@ struct volym_ctx {
         int dilate = -1;
         uint32_t grid = 0;                       // workgroups of the captured launch
         uint32_t dev_drop_tenths = 0;            // dev
-        uint32_t dp_floor = 104;
+        uint32_t dp_floor = 64;
         uint32_t trim_rounds = 0;
         double t_us[6] = {};                     // dev: wall-clock stamps of the job's stages
         uint32_t prio_tenths[3] = {3, 6, 10};
@@ -153,7 +153,7 @@ struct volym_ctx {
     uint32_t prio_tenths[3] = {3, 6, 10};
     bool dev_only_quarters = false;
     uint32_t dev_drop_tenths = 0;
-    uint32_t dp_floor = 104;                     // floor of the adaptive split threshold, cost units (deal_list)
+    uint32_t dp_floor = 64;                      // floor of the adaptive split threshold, cost units (deal_list)
     bool bricked = false;
     uint64_t brick_from_bytes = 64ull << 20;
     int layout_choice = -1;

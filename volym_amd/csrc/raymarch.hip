@@ -310,26 +310,16 @@ static void deal_list(const volym_ctx* c, const volym_ctx::FbJob& job, const std
     uint64_t total_cost = 0;
     for (uint32_t item : geometric) total_cost += item_cost[item];
     const uint32_t resident_waves = std::max(1u, job.max_grid * waves);
-    // measured optimum: 1.5x for the table mode, 1.2x for the continuous-rho modes (their classic loop speculates only two
-    // samples deep, a depth-parallel item four)
-    const uint64_t tenths = job.dp_min_cost < -1 ? static_cast<uint64_t>(-job.dp_min_cost) : (job.continuous ? 12u : 15u);
-    // ... with a floor for the frames that are bound by the time of their long tiles rather than by throughput.  When culling leaves
-    // little other work the fair share shrinks, the rule above splits twice as many tiles, and the frame gets slower (1080p
-    // bonsai with the tile mask: 35.7 us instead of 32.3): a split tile's quarters still take ~0.55-0.65 of the tile's own time, so
-    // below ~0.65 x the heaviest tiles splitting adds work and shortens nothing.  Measured optima: 104-114 units on the 1080p
-    // bonsai (heaviest tiles ~200); the teapot at 1024x768 wants the first rule alone at steps 0.003-0.005 (its frames are
-    // throughput-bound, 55-75 us; the 0.55 rule alone costs it 10-15 %) and at step 0.02 (27 us; no heavy tiles: an absolute
-    // floor alone costs it 20 %).  Hence the smaller of the two: an absolute 104 units (a tile of ~30 us), and 0.65 x the 4th
-    // heaviest tile (one freak tile does not move it).
-    uint64_t floor_cost = 64u;
-    if (job.dp_min_cost == -1 && job.plain) {                   // (look-ahead and continuous-rho iterations cost more per unit)
-        uint16_t top[4] = {0, 0, 0, 0};
-        for (uint32_t item : geometric) {
-            uint16_t k = item_cost[item];
-            for (int i = 0; i < 4; ++i) if (k > top[i]) std::swap(k, top[i]);
-        }
-        floor_cost = std::max<uint64_t>(64u, std::min<uint64_t>(job.dp_floor, static_cast<uint64_t>(top[3]) * 65u / 100u));
-    }
+    // Measured over four scenes (profiles/r03_dp_scene_sweep.txt: bonsai, teapot, a dense ball, thin vessels; 1080p, where the
+    // split matters -- at 3840x2160 every setting gives the same frame time): the common instantiation wants 1.7-1.9x (bonsai
+    // 33.9 us at 1.9x against 34.3 with r02's rule, teapot 44.9 against 51.9, ball 54.1 against 60.9; the vessels do not
+    // care); r02's 1.5x with an absolute floor of 104 units was the optimum of the bonsai alone and cost the other scenes
+    // 10-17 %.  The look-ahead instantiations keep 1.5x, the continuous-rho modes 1.2x (their classic loop speculates only
+    // two samples deep, a depth-parallel item four), as measured in r01 / r02.  A list dealt for a moving camera is read on later
+    // views: there the lower threshold (more tiles split than the captured view needed) is the better one (turntable at 0.25
+    // degrees per frame: 53.4 us at 1.5x, 57.0 at 1.9x).
+    const uint64_t tenths = job.dp_min_cost < -1 ? static_cast<uint64_t>(-job.dp_min_cost) : (job.continuous ? 12u : (job.plain && !moving) ? 19u : 15u);
+    const uint64_t floor_cost = job.dp_floor;                                   // 64 units: a tile below that is never worth four waves
     const uint32_t adaptive = static_cast<uint32_t>(std::max<uint64_t>(floor_cost, tenths * total_cost / (10u * resident_waves) + 16));
     const uint32_t dp_thr = job.dp_min_cost < 0 ? adaptive : static_cast<uint32_t>(job.dp_min_cost);
 #if VOLYM_DEV_SWITCHES

@@ -154,6 +154,63 @@ def synth_teapot(nx=256, ny=256, nz=178, seed=DEFAULT_SEED):
     return vol.reshape(-1), lab.reshape(-1)
 
 
+def synth_ball(n=256, seed=DEFAULT_SEED):
+    """n^3 uint8: one ball of radius 0.36 n whose value rises from 48 at its surface to 208 at its centre (+- 8 noise): every
+    ray through it is one long run of dense samples of slowly growing opacity.  A scene for the scheduling rows (long chains
+    of dependent samples everywhere, no thin structure)."""
+    vol = np.empty((n, n, n), np.uint8)
+    x = np.arange(n, dtype=np.int64)[None, :]
+    y = np.arange(n, dtype=np.int64)[:, None]
+    c, r = n // 2, (36 * n) // 100
+    for z in range(n):
+        h = _slice_hash(n, n, z, seed + 7)
+        s = (h & np.uint32(7)).astype(np.int64)
+        d2 = (x - c) ** 2 + (y - c) ** 2 + (z - c) ** 2
+        inside = d2 < r * r
+        noise = ((h >> np.uint32(12)) & np.uint32(15)).astype(np.int64) - 8
+        val = 208 - (160 * d2) // (r * r) + noise
+        s[inside] = val[inside]
+        vol[z] = np.clip(s, 0, 255).astype(np.uint8)
+    return vol.reshape(-1)
+
+
+def synth_vessels(n=256, seed=DEFAULT_SEED):
+    """n^3 uint8: 48 thin tubes (radius 0.008-0.02 n, value 176..223) along slowly bending paths through the volume, air noise
+    0..7: a sparse scene -- most rays that come near anything miss it, the hits are short dense runs."""
+    vol = np.empty((n, n, n), np.uint8)
+    x = np.arange(n, dtype=np.int64)[None, :]
+    y = np.arange(n, dtype=np.int64)[:, None]
+    tubes = []
+    for i in range(48):
+        h = [_hash_scalar(seed * 57 + 8 * i + k) for k in range(8)]
+        # centre line (x, y) as a function of z: a + b * z / n + c * tri(z), integers in 1/1024 voxel units
+        ax, ay = (n // 8 + (h[0] % 1024) * (3 * n // 4) // 1024) * 1024, (n // 8 + (h[1] % 1024) * (3 * n // 4) // 1024) * 1024
+        bx, by = (h[2] % 2048 - 1024) * (n // 4), (h[3] % 2048 - 1024) * (n // 4)          # drift over the whole depth, +- n/4 voxels
+        cx, cy = (h[4] % 1024) * (n // 16), (h[5] % 1024) * (n // 16)                      # wobble amplitude, up to n/16 voxels
+        period = n // 4 + (h[6] % 1024) * (n // 2) // 1024
+        rad = max((8 * n) // 1000 + (h[7] % 1024) * ((12 * n) // 1000) // 1024, 1)
+        tubes.append((ax, ay, bx, by, cx, cy, max(period, 4), rad))
+    for z in range(n):
+        h = _slice_hash(n, n, z, seed + 11)
+        s = (h & np.uint32(7)).astype(np.int64)
+        tv = 176 + ((h >> np.uint32(8)) & np.uint32(47)).astype(np.int64)
+        for (ax, ay, bx, by, cx, cy, period, rad) in tubes:
+            ph = z % period
+            tri = (4096 * ph) // period - 1024 if ph * 2 < period else 3072 - (4096 * ph) // period      # triangle wave in [-1024, 1024]
+            px = (ax + (bx * z) // n + (cx * tri) // 1024) // 1024
+            py = (ay + (by * z) // n + (cy * tri) // 1024) // 1024
+            x0, x1 = max(px - rad, 0), min(px + rad + 1, n)
+            y0, y1 = max(py - rad, 0), min(py + rad + 1, n)
+            if x0 >= x1 or y0 >= y1:
+                continue
+            d2 = (x[:, x0:x1] - px) ** 2 + (y[y0:y1, :] - py) ** 2
+            sub = s[y0:y1, x0:x1]
+            upd = d2 <= rad * rad
+            sub[upd] = tv[y0:y1, x0:x1][upd]
+        vol[z] = s.astype(np.uint8)
+    return vol.reshape(-1)
+
+
 def constant_cube(n, value):
     return np.full(n * n * n, value, np.uint8)
 
