@@ -1075,7 +1075,8 @@ static int ensure_frame_resources(volym_ctx* c)
 {
     if (c->df_thr_byte != c->thr_byte_cull) {
         // stream order: earlier frames finish reading d_df before this kernel rewrites it
-        hipLaunchKernelGGL(volym_distance_field_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_mc, c->d_df, c->d_aabb, c->mc_n, c->thr_byte_cull);
+        if (c->mc_n <= 32u) hipLaunchKernelGGL(volym_distance_field_kernel<1>, dim3(1), dim3(1024), 0, c->stream, c->d_mc, c->d_df, c->d_aabb, c->mc_n, c->thr_byte_cull);
+        else hipLaunchKernelGGL(volym_distance_field_kernel<4>, dim3(1), dim3(1024), 0, c->stream, c->d_mc, c->d_df, c->d_aabb, c->mc_n, c->thr_byte_cull);
         HIPCHK(c, hipGetLastError());
         c->df_thr_byte = c->thr_byte_cull;
         c->hull_dirty = true;

@@ -299,13 +299,13 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
 // (n <= 64: at most four).  mask_0 = occupied, mask_k = mask_{k-1} dilated by one cell along x, y and z (a 3x3x3 box); the
 // masks are nested, so D(c) = #{k in 0..14 : c not in mask_k}, accumulated in four bit planes.
 constexpr uint32_t VOLYM_DF_MAX_N = 64;
+template <int RPT>     // rows per thread: 1 for grids up to 32^3, 4 up to 64^3
 __global__ __launch_bounds__(1024) void volym_distance_field_kernel(const uint8_t* __restrict__ mc_max, uint8_t* __restrict__ df4,
                                                                     int* __restrict__ aabb, uint32_t mc_n, uint32_t thr_byte)
 {
     typedef unsigned long long u64;
-    constexpr int RPT = (VOLYM_DF_MAX_N * VOLYM_DF_MAX_N) / 1024;     // rows per thread
-    __shared__ u64 rows[VOLYM_DF_MAX_N * VOLYM_DF_MAX_N];
-    __shared__ u64 tmp[VOLYM_DF_MAX_N * VOLYM_DF_MAX_N];
+    __shared__ u64 rows[RPT * 1024];
+    __shared__ u64 tmp[RPT * 1024];
     __shared__ int s_box[6];
     const uint32_t n = mc_n, n_rows = n * n;
     if (threadIdx.x < 6u) s_box[threadIdx.x] = (threadIdx.x < 3u) ? static_cast<int>(n) : -1;
