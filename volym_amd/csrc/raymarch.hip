@@ -1237,7 +1237,7 @@ static int launch_march(volym_ctx* c)
         const uint32_t per_chunk = (c->n_local + chunks - 1u) / chunks;
         grid = per_chunk * chunks;
     }
-    Counters* cnt = COUNT ? c->d_counters : nullptr;
+    Counters* cnt = (COUNT || (VOLYM_DEV_SWITCHES && (c->fp.dev & 512u))) ? c->d_counters : nullptr;
     uint4* trace = TRACE ? c->d_trace : nullptr;
     if (!COUNT && !TRACE && frame_uses_pool(c, fp.flags)) {
         // the ray pool (raymarch_pool.h): the common instantiation; every other flag set runs variant 2 below
@@ -1634,6 +1634,17 @@ int volym_dev_pool_timeline(volym_ctx* c, int on, uint32_t* out, uint32_t max_wo
     if (out && words) HIPCHK(c, hipMemcpy(out, c->d_pool_dbg, static_cast<size_t>(words) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     c->pool_dbg = on != 0;
     return static_cast<int>(words);
+}
+
+// development: the raw counters (fp.dev & 512: the cone-job debug counts of the plain launches since the last reset); reset != 0 zeroes them
+int volym_dev_counters(volym_ctx* c, unsigned long long out[5], int reset)
+{
+    if (!c) return VOLYM_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out) HIPCHK(c, hipMemcpy(out, c->d_counters, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(c, hipMemset(c->d_counters, 0, sizeof(Counters)));
+    return VOLYM_OK;
 }
 
 int volym_dev_read_costs(volym_ctx* c, uint16_t* out, uint32_t max_items)

@@ -46,6 +46,8 @@
 // The instrumented (COUNT) launch disables culling: it counts what the reference would fetch.
 #pragma once
 
+#include <type_traits>
+
 #include "raymarch_device.h"
 
 namespace volym {
@@ -140,7 +142,13 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     __shared__ float s_qr[TABLE ? 1 : WAVES][TABLE ? 1 : PQ_QCAP];
     __shared__ uint32_t s_acc[WAVES][3][64];
     __shared__ float4 s_hh[WAVES][64];                  // per ray of the wave's tile: the Blinn-Phong half vector (a constant of the ray)
-    __shared__ uint8_t s_mail[(IMP || IR) ? WAVES : 1][(IMP || IR) ? 256 : 1];   // look-ahead candidates of a wave (ahead_straight_wave)
+    __shared__ uint8_t s_mail[(IMP || IR) ? WAVES : 1][(IMP || IR) ? 256 : 1];   // look-ahead candidates of a wave (ahead_straight_wave); cone jobs: the verdicts
+    uint8_t (*const s_cres)[(IMP || IR) ? 256 : 1] = s_mail;      // per wave, [k][lane]: 0 pending, 1 nothing important ahead, 2 important ahead (a frame uses one of the two look-aheads)
+    // IR: the cone look-ahead's walks, shared by the waves of the workgroup (below, "cone jobs")
+    constexpr uint32_t CJ_CAP = 32;      // (a window: a wave with more samples to ask about serves jobs until there is room)
+    __shared__ float4 s_cj[IR ? 2 * CJ_CAP : 1];        // {start.xyz, step} {dir.xyz, owner wave | k << 4 | lane << 6}
+    __shared__ uint32_t s_cj_flag[IR ? CJ_CAP : 1];     // 0: free, 2: being written, 1: written and not yet taken
+    __shared__ uint32_t s_cj_ctl[4];                    // head, tail, waves that may still submit
     __shared__ uint32_t s_next_ticket;
     __shared__ uint2 s_items[PQ_ITEMS_LDS];             // this workgroup's work list (entries b, b+G, ...): {item code, tile x | tile y << 16}
 
@@ -170,6 +178,10 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     {
         const uint32_t i = threadIdx.x;
         if (i == 0u) s_next_ticket = 0u;
+        if (IR) {
+            for (uint32_t k = i; k < CJ_CAP; k += THREADS) s_cj_flag[k] = 0u;
+            if (i == 0u) { s_cj_ctl[0] = 0u; s_cj_ctl[1] = 0u; s_cj_ctl[2] = WAVES; }
+        }
         for (uint32_t k = i; k < PQ_ITEMS_LDS; k += THREADS) {
             const size_t gi = blockIdx.x + static_cast<size_t>(gridDim.x) * k;
             if (gi < n_items) s_items[k] = order[gi];
@@ -219,6 +231,173 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     };
     const bool culling = !COUNT && fp.cull != 0u;
     const HullEdge hull_edge = load_hull_edge(fp, lane);
+
+    // ---- cone jobs (IR, use_cone_importance_check): the 8 x N probes of a sample's look-ahead (wgsl:94-139) are the bulk of such a
+    // frame, and they sit in the few tiles that show unimportant matter in front of important matter -- one wave per tile walked
+    // them while the other waves of its workgroup had long finished (r02: 298 us per frame).  So the walks are jobs in a ring in LDS:
+    // the wave that needs them writes {start, step, direction, who asked} records, ANY wave of the workgroup takes 8 records at a
+    // time (8 samples x 8 directions on its 64 lanes, as ahead_cone_wave does), and writes one result byte per sample.  The asking
+    // wave serves jobs itself while it waits, and a wave that has run out of tiles serves until every wave has: no wave ever
+    // waits for anything but a job that some wave -- if need be itself -- is free to run.  Same positions and f32 operations per
+    // direction as ahead_cone; every wait is bounded.
+    auto cj_serve = [&]() __attribute__((always_inline)) -> bool {
+        uint32_t h = 0, n = 0;
+        if (lane == 0u) {
+            for (;;) {
+                h = *reinterpret_cast<volatile uint32_t*>(&s_cj_ctl[0]);
+                const uint32_t tl = *reinterpret_cast<volatile uint32_t*>(&s_cj_ctl[1]);
+                n = min(8u, tl - h);
+                if (n == 0u || atomicCAS(&s_cj_ctl[0], h, h + n) == h) break;
+            }
+        }
+        h = __builtin_amdgcn_readfirstlane(h); n = __builtin_amdgcn_readfirstlane(n);
+        if (n == 0u) return false;
+        if (VOLYM_DEV_SWITCHES && (fp.dev & 512u) && lane == 0u) atomicAdd(&counters->n_imp, static_cast<unsigned long long>(n));      // debug: records taken
+        const uint32_t c = lane >> 3;
+        const bool job = c < n;
+        const uint32_t idx = (h + c) & (CJ_CAP - 1u);
+        // Take a record out of the place: 1 written -> 3 taken (exclusive: places are reserved a lap apart, two servers can be
+        // looking at one place), copy it, free the place at once (-> 0).  A group of eight lanes that has its record does not hold
+        // the place while its siblings wait for theirs: nobody holds one thing and waits for another, so no circle of waits.
+        bool job_ok = false;
+        float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0;
+        {
+            bool have = !job;
+            uint32_t spins = 0;
+            while (!have) {
+                uint32_t st = 0;
+                if ((lane & 7u) == 0u) st = atomicCAS(&s_cj_flag[idx], 1u, 3u) == 1u ? 1u : 0u;
+                st = __shfl(st, static_cast<int>(lane & ~7u), 64);
+                if (st != 0u) {
+                    r0 = s_cj[2u * idx]; r1 = s_cj[2u * idx + 1u];
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if ((lane & 7u) == 0u) *reinterpret_cast<volatile uint32_t*>(&s_cj_flag[idx]) = 0u;
+                    have = true; job_ok = true;
+                } else {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins >= (1u << 20)) {                 // cannot happen; never hang
+                        have = true;
+                        if (VOLYM_DEV_SWITCHES && (fp.dev & 512u) && (lane & 7u) == 0u) atomicAdd(&counters->n_hit, 1ull);   // debug: a record that never came
+                    }
+                }
+            }
+        }
+        const V3 p0 = v3(r0.x, r0.y, r0.z), d0 = v3(r1.x, r1.y, r1.z);
+        const float step = r0.w;
+        const uint32_t meta = __float_as_uint(r1.w);
+        const int nprobe = static_cast<int>(fp.ahead_steps);
+        const float cone_xo = fp.cone_cos[lane & 7u] * 0.2f, cone_yo = fp.cone_sin[lane & 7u] * 0.2f;
+        const V3 right = normalize_exact(cross(d0, v3(0.0f, 1.0f, 0.0f)));       // wgsl:99-113, as ahead_cone
+        const V3 new_up = cross(d0, right);
+        const V3 sd = normalize_exact((d0 + right * cone_xo) + new_up * cone_yo);
+        V3 pos = p0;
+        bool left = !job_ok, hit = false;                                          // left: this direction has left [0,1]^3 (wgsl:122-124)
+        for (int i = 0; i < nprobe; i += VOLYM_PROBE_BATCH) {
+            uint32_t ib[VOLYM_PROBE_BATCH];
+            bool out[VOLYM_PROBE_BATCH];
+#pragma unroll
+            for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
+                pos = pos + sd * step;
+                out[j] = outside01(pos);
+                ib[j] = imp[nearest_offset(g, pos)];                              // clamped offset: safe wherever pos is
+            }
+#pragma unroll
+            for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
+                if (!left && !hit && i + j < nprobe) {
+                    if (out[j]) left = true;
+                    else if (ib[j] >= 128u) hit = true;                           // i/255 >= 0.5  <=>  i >= 128
+                }
+            }
+            const unsigned long long hit_now = __ballot(hit);                     // one direction's hit decides the sample (wgsl:108-139 returns there)
+            if (((hit_now >> (lane & 56u)) & 0xffull) != 0ull) left = true;
+            if (__ballot(!left && !hit) == 0ull) break;
+        }
+        const unsigned long long hits = __ballot(hit);
+        if (job_ok && (lane & 7u) == 0u)
+            *reinterpret_cast<volatile uint8_t*>(&s_cres[meta & 15u][((meta >> 4) & 3u) * 64u + ((meta >> 6) & 63u)]) = ((hits >> (lane & 56u)) & 0xffull) != 0ull ? 2 : 1;
+        return true;
+    };
+    // the look-aheads of up to NK samples per lane (sample k at o + d * tsk[k]): submit, serve while waiting, read the verdicts.
+    // One loop, one place that serves: a turn either submits the next k, or finds every verdict in, or walks somebody's job.
+    auto cj_lookahead = [&](const auto& need_in, const auto& tsk, V3 org, V3 dir, float t_exit, auto& found) __attribute__((always_inline)) {
+        constexpr int NK = static_cast<int>(sizeof(tsk) / sizeof(tsk[0]));
+        uint32_t need_bits = 0;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { found[k] = false; any = any || need_in[k]; }
+        if (__ballot(any) == 0ull) return;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const bool nd = need_in[k] && !ahead_cannot_hit(fp, org + dir * tsk[k], dir, t_exit, true);   // cannot reach an important voxel: false, unwalked
+            need_bits |= nd ? 1u << k : 0u;
+            if (nd) *reinterpret_cast<volatile uint8_t*>(&s_cres[wave][k * 64 + lane]) = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        uint32_t k = 0, todo_bits = need_bits;                                    // todo: not yet in the ring
+        for (uint32_t turns = 0; turns < (1u << 16); ++turns) {
+            if (k < static_cast<uint32_t>(NK)) {
+                const bool mine = ((todo_bits >> k) & 1u) != 0u;
+                const unsigned long long m = __ballot(mine);
+                if (m == 0ull) { k++; continue; }
+                const uint32_t n = static_cast<uint32_t>(__popcll(m));
+                uint32_t got = 0, tl = 0;
+                if (lane == 0u) {                                                 // as many of the n records as there is room for (serving makes room)
+                    const uint32_t hd = *reinterpret_cast<volatile uint32_t*>(&s_cj_ctl[0]);
+                    tl = *reinterpret_cast<volatile uint32_t*>(&s_cj_ctl[1]);
+                    const uint32_t room = CJ_CAP - min(CJ_CAP, tl - hd);
+                    got = min(n, room);
+                    if (got != 0u && atomicCAS(&s_cj_ctl[1], tl, tl + got) != tl) got = 0;
+                }
+                got = __builtin_amdgcn_readfirstlane(got);
+                const uint32_t first_pos = __builtin_amdgcn_readfirstlane(tl);       // (read here, where lane 0 is active)
+                if (got != 0u) {
+                    const uint32_t rank = lane_rank_in_mask(m);
+                    if (mine && rank < got) {
+                        float tk = tsk[0];
+#pragma unroll
+                        for (int q = 1; q < NK; ++q) tk = k == static_cast<uint32_t>(q) ? tsk[q] : tk;
+                        const V3 start = org + dir * tk;                          // the sample position, as its owner computes it (wgsl:251)
+                        const uint32_t idx = (first_pos + rank) & (CJ_CAP - 1u);
+                        const float step = (t_exit - length_exact(start)) / static_cast<float>(static_cast<int>(fp.ahead_steps));   // wgsl:111
+                        // Take the place (0 free -> 2 being written -> 1 written): a place can be reserved a lap apart by two waves while its
+                        // last taker still reads it, and only one of them may write next.  Every lane writes in the very turn it gets its
+                        // place -- a lane that waited for its siblings' places would close a circle of waits (a server holds back a place
+                        // until all eight of its records are there, one of which is this wave's).
+                        bool written = false;
+                        uint32_t spins = 0;
+                        while (!written) {
+                            if (atomicCAS(&s_cj_flag[idx], 0u, 2u) == 0u) {
+                                s_cj[2u * idx] = make_float4(start.x, start.y, start.z, step);
+                                s_cj[2u * idx + 1u] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(wave | (k << 4) | (lane << 6)));
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                                *reinterpret_cast<volatile uint32_t*>(&s_cj_flag[idx]) = 1u;
+                                written = true;
+                            } else {
+                                __builtin_amdgcn_s_sleep(1);
+                                if (++spins >= (1u << 20)) {                      // cannot happen (see above); never hang: the verdict is "nothing ahead"
+                                    *reinterpret_cast<volatile uint8_t*>(&s_cres[wave][k * 64 + lane]) = 1;
+                                    written = true;
+                                    if (VOLYM_DEV_SWITCHES && (fp.dev & 512u)) atomicAdd(&counters->n_dense, 1ull);
+                                }
+                            }
+                        }
+                        todo_bits &= ~(1u << k);
+                        if (VOLYM_DEV_SWITCHES && (fp.dev & 512u)) atomicAdd(&counters->n_vol, 1ull);   // debug: records written
+                    }
+                    if (got == n) { k++; continue; }                              // (else: the rest of this k after a job or two)
+                }
+            } else {
+                bool pending = false;
+#pragma unroll
+                for (int q = 0; q < NK; ++q) pending = pending || (((need_bits >> q) & 1u) != 0u && *reinterpret_cast<volatile uint8_t*>(&s_cres[wave][q * 64 + lane]) == 0);
+                if (__ballot(pending) == 0ull) break;
+            }
+            if (!cj_serve()) __builtin_amdgcn_s_sleep(1);
+            if (VOLYM_DEV_SWITCHES && (fp.dev & 512u) && turns + 1u == (1u << 16) && lane == 0u) atomicAdd(&counters->n_steps, 1ull);       // debug: a look-ahead that gave up
+        }
+#pragma unroll
+        for (int q = 0; q < NK; ++q) found[q] = ((need_bits >> q) & 1u) != 0u && *reinterpret_cast<volatile uint8_t*>(&s_cres[wave][q * 64 + lane]) == 2;
+    };
     // this lane's cone direction (lane & 7) for the wave-wide cone look-ahead, computed where it is used (two gathers
     // from the kernel-argument segment and two multiplies per call: nothing kept live across the march)
     for (uint32_t ticket = grab(); ticket < n_mine; ticket = grab()) {
@@ -584,9 +763,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
 #pragma unroll
                         for (int j = 0; j < J; ++j) { need[j] = active && my_b[j] >= fp.thr_byte && my_ib[j] < 255u; ahead[j] = false; }
                         if (flags & F_CONE) {
-#pragma unroll
-                            for (int j = 0; j < J; ++j)
-                                ahead[j] = ahead_cone_wave(g, fp, need[j], my_pos[j], ray.d, ray.t_exit, lane, fp.cone_cos[lane & 7u] * 0.2f, fp.cone_sin[lane & 7u] * 0.2f);
+                            cj_lookahead(need, my_t, ray.o, ray.d, ray.t_exit, ahead);
                         } else {
                             bool any_need = false;
 #pragma unroll
@@ -833,9 +1010,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                         chain = chain && dense_k == predicted;
                     }
                     if (flags & F_CONE) {
-#pragma unroll
-                        for (int k = 0; k < K; ++k)
-                            supp[k] = ahead_cone_wave(g, fp, need[k], ray.o + ray.d * ts[k], ray.d, ray.t_exit, lane, fp.cone_cos[lane & 7u] * 0.2f, fp.cone_sin[lane & 7u] * 0.2f);
+                        cj_lookahead(need, ts, ray.o, ray.d, ray.t_exit, supp);
                     } else {
                         bool any_need = false;
 #pragma unroll
@@ -995,6 +1170,16 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
       }
     }
 
+    if (IR && (flags & F_CONE)) {
+        // out of tiles: walk the other waves' cone jobs until every wave of the workgroup is out of tiles
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane == 0u) atomicSub(&s_cj_ctl[2], 1u);
+        for (uint32_t turns = 0; turns < (1u << 20); ++turns) {
+            if (cj_serve()) continue;
+            if (*reinterpret_cast<volatile uint32_t*>(&s_cj_ctl[2]) == 0u) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
     if (cost && lane == 0) wg_time[blockIdx.x * WAVES + wave] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
     if (TRACE) for (int sft = 32; sft > 0; sft >>= 1) trace_accepted += __shfl_xor(trace_accepted, sft, 64);
     if (TRACE && lane == 0) {
