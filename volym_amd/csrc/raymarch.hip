@@ -1278,27 +1278,33 @@ static int launch_march(volym_ctx* c)
         const uint32_t waves = ((table && no_imp) || !wide12) ? PQ_WAVES : PQ_WAVES_WIDE;
         const uint32_t want = (n_items + waves - 1) / waves;
         const uint32_t pgrid = wl.grid ? wl.grid : std::max(1u, std::min(want, max_grid(c)));
-#define VOLYM_PQ_LAUNCH(T, KS, I, B, R, WV)                                                                                      \
-    hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT && I, TRACE, KS, I, B, R, WV>), dim3(pgrid), dim3(WV * 64), 0, c->stream, c->d_vol,  \
+#define VOLYM_PQ_LAUNCH_J(T, KS, I, B, R, WV, J)                                                                                 \
+    hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT && I, TRACE, KS, I, B, R, WV, J>), dim3(pgrid), dim3(WV * 64), 0, c->stream, c->d_vol,  \
                        c->d_imp, c->d_tables, c->d_df, reinterpret_cast<const uint2*>(c->d_list[c->cur]), n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
+#define VOLYM_PQ_LAUNCH(T, KS, I, B, R, WV) VOLYM_PQ_LAUNCH_J(T, KS, I, B, R, WV, false)
 #if VOLYM_DEV_SWITCHES
 #define VOLYM_PQ_LAUNCH_W(T, KS, I, B, R) do { if (wide12) VOLYM_PQ_LAUNCH(T, KS, I, B, R, PQ_WAVES_WIDE); else VOLYM_PQ_LAUNCH(T, KS, I, B, R, PQ_WAVES); } while (0)
 #else
 #define VOLYM_PQ_LAUNCH_W(T, KS, I, B, R) VOLYM_PQ_LAUNCH(T, KS, I, B, R, PQ_WAVES)
 #endif
+        // the cone look-ahead of the importance-rendering instantiation: its walks as jobs shared by the workgroup (raymarch_pq.h CJ)
+        const bool cone_jobs = ir && (fp.flags & F_CONE) != 0u && !TRACE;
         if (c->bricked) {
             if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, true, false, PQ_WAVES);
+            else if (table && ir && cone_jobs) VOLYM_PQ_LAUNCH_J(true, 4, false, true, true, PQ_WAVES, true);
             else if (table && ir) { if (wide12) VOLYM_PQ_LAUNCH(true, 4, false, true, true, PQ_WAVES_WIDE); else VOLYM_PQ_LAUNCH(true, 4, false, true, true, PQ_WAVES); }
             else if (table) VOLYM_PQ_LAUNCH_W(true, 4, true, true, false);
             else VOLYM_PQ_LAUNCH_W(false, 1, true, true, false);
         } else {
             if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, false, false, PQ_WAVES);
+            else if (table && ir && cone_jobs) VOLYM_PQ_LAUNCH_J(true, 4, false, false, true, PQ_WAVES, true);
             else if (table && ir) VOLYM_PQ_LAUNCH_W(true, 4, false, false, true);
             else if (table) VOLYM_PQ_LAUNCH_W(true, 4, true, false, false);
             else VOLYM_PQ_LAUNCH_W(false, 1, true, false, false);
         }
 #undef VOLYM_PQ_LAUNCH_W
 #undef VOLYM_PQ_LAUNCH
+#undef VOLYM_PQ_LAUNCH_J
         HIPCHK(c, hipGetLastError());
         if (capture) {
             // costs -> pinned host memory on the copy stream, behind this launch; the feedback thread takes it from there

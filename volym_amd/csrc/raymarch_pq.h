@@ -115,7 +115,8 @@ __device__ __forceinline__ bool tile_mask_bit(const FrameParams& fp, uint32_t t8
 // WAVES: waves per workgroup.  16 (four per SIMD, a budget of 128 VGPRs) for the common instantiation, which fits; the
 // importance / continuous-rho instantiations need ~150 registers and run 12 waves (three per SIMD, 168 VGPRs) instead of
 // spilling 64-100 bytes per lane to scratch (profiles/r02_kernel_resources.txt).
-template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true, bool BRICK = false, bool IR = false, int WAVES = PQ_WAVES>
+// CJ (with IR): the cone look-ahead's walks as jobs shared by the waves of the workgroup ("cone jobs" below)
+template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true, bool BRICK = false, bool IR = false, int WAVES = PQ_WAVES, bool CJ = false>
 __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
     const uint8_t* __restrict__ df4, const uint2* __restrict__ order, uint32_t n_items, uint16_t* __restrict__ cost,
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     constexpr int K = TABLE ? KSPEC : 2;     // speculation depth (continuous-rho modes: 2 -- each sample is 5-8 gathers)
     constexpr int PQ_QCAP = pq_qcap(K);
     static_assert(K <= 4, "the shading queue of K > 4 does not fit the LDS");
+    static_assert(!CJ || IR, "cone jobs belong to the importance-rendering instantiation");
     unsigned long long trace_t0 = 0;
     uint32_t trace_iters = 0, trace_flushes = 0, trace_tiles = 0, trace_marched = 0, trace_lanes = 0, trace_accepted = 0, trace_dp_iters = 0;
     unsigned long long tm_leap = 0, tm_samp = 0, tm_flush = 0, tm_mark = 0;
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     uint8_t (*const s_cres)[(IMP || IR) ? 256 : 1] = s_mail;      // per wave, [k][lane]: 0 pending, 1 nothing important ahead, 2 important ahead (a frame uses one of the two look-aheads)
     // IR: the cone look-ahead's walks, shared by the waves of the workgroup (below, "cone jobs")
     constexpr uint32_t CJ_CAP = 32;      // (a window: a wave with more samples to ask about serves jobs until there is room)
-    __shared__ float4 s_cj[IR ? 2 * CJ_CAP : 1];        // {start.xyz, step} {dir.xyz, owner wave | k << 4 | lane << 6}
-    __shared__ uint32_t s_cj_flag[IR ? CJ_CAP : 1];     // 0: free, 2: being written, 1: written and not yet taken
+    __shared__ float4 s_cj[CJ ? 2 * CJ_CAP : 1];        // {start.xyz, step} {dir.xyz, owner wave | k << 4 | lane << 6}
+    __shared__ uint32_t s_cj_flag[CJ ? CJ_CAP : 1];     // 0: free, 2: being written, 1: written and not yet taken
     __shared__ uint32_t s_cj_ctl[4];                    // head, tail, waves that may still submit
     __shared__ uint32_t s_next_ticket;
     __shared__ uint2 s_items[PQ_ITEMS_LDS];             // this workgroup's work list (entries b, b+G, ...): {item code, tile x | tile y << 16}
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     {
         const uint32_t i = threadIdx.x;
         if (i == 0u) s_next_ticket = 0u;
-        if (IR) {
+        if (CJ) {
             for (uint32_t k = i; k < CJ_CAP; k += THREADS) s_cj_flag[k] = 0u;
             if (i == 0u) { s_cj_ctl[0] = 0u; s_cj_ctl[1] = 0u; s_cj_ctl[2] = WAVES; }
         }
@@ -286,31 +288,34 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         const float step = r0.w;
         const uint32_t meta = __float_as_uint(r1.w);
         const int nprobe = static_cast<int>(fp.ahead_steps);
-        const float cone_xo = fp.cone_cos[lane & 7u] * 0.2f, cone_yo = fp.cone_sin[lane & 7u] * 0.2f;
-        const V3 right = normalize_exact(cross(d0, v3(0.0f, 1.0f, 0.0f)));       // wgsl:99-113, as ahead_cone
-        const V3 new_up = cross(d0, right);
-        const V3 sd = normalize_exact((d0 + right * cone_xo) + new_up * cone_yo);
-        V3 pos = p0;
-        bool left = !job_ok, hit = false;                                          // left: this direction has left [0,1]^3 (wgsl:122-124)
-        for (int i = 0; i < nprobe; i += VOLYM_PROBE_BATCH) {
-            uint32_t ib[VOLYM_PROBE_BATCH];
-            bool out[VOLYM_PROBE_BATCH];
+        bool hit = false;
+        {
+            const float cone_xo = fp.cone_cos[lane & 7u] * 0.2f, cone_yo = fp.cone_sin[lane & 7u] * 0.2f;
+            const V3 right = normalize_exact(cross(d0, v3(0.0f, 1.0f, 0.0f)));       // wgsl:99-113, as ahead_cone
+            const V3 new_up = cross(d0, right);
+            const V3 sd = normalize_exact((d0 + right * cone_xo) + new_up * cone_yo);
+            V3 pos = p0;
+            bool left = !job_ok;                                                       // left: this direction has left [0,1]^3 (wgsl:122-124)
+            for (int i = 0; i < nprobe; i += VOLYM_PROBE_BATCH) {
+                uint32_t ib[VOLYM_PROBE_BATCH];
+                bool out[VOLYM_PROBE_BATCH];
 #pragma unroll
-            for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
-                pos = pos + sd * step;
-                out[j] = outside01(pos);
-                ib[j] = imp[nearest_offset(g, pos)];                              // clamped offset: safe wherever pos is
-            }
-#pragma unroll
-            for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
-                if (!left && !hit && i + j < nprobe) {
-                    if (out[j]) left = true;
-                    else if (ib[j] >= 128u) hit = true;                           // i/255 >= 0.5  <=>  i >= 128
+                for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
+                    pos = pos + sd * step;
+                    out[j] = outside01(pos);
+                    ib[j] = imp[nearest_offset(g, pos)];                              // clamped offset: safe wherever pos is
                 }
+#pragma unroll
+                for (int j = 0; j < VOLYM_PROBE_BATCH; ++j) {
+                    if (!left && !hit && i + j < nprobe) {
+                        if (out[j]) left = true;
+                        else if (ib[j] >= 128u) hit = true;                           // i/255 >= 0.5  <=>  i >= 128
+                    }
+                }
+                const unsigned long long hit_now = __ballot(hit);                     // one direction's hit decides the sample (wgsl:108-139 returns there)
+                if (((hit_now >> (lane & 56u)) & 0xffull) != 0ull) left = true;
+                if (__ballot(!left && !hit) == 0ull) break;
             }
-            const unsigned long long hit_now = __ballot(hit);                     // one direction's hit decides the sample (wgsl:108-139 returns there)
-            if (((hit_now >> (lane & 56u)) & 0xffull) != 0ull) left = true;
-            if (__ballot(!left && !hit) == 0ull) break;
         }
         const unsigned long long hits = __ballot(hit);
         if (job_ok && (lane & 7u) == 0u)
@@ -762,9 +767,15 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                         bool need[J], ahead[J];
 #pragma unroll
                         for (int j = 0; j < J; ++j) { need[j] = active && my_b[j] >= fp.thr_byte && my_ib[j] < 255u; ahead[j] = false; }
-                        if (flags & F_CONE) {
+                        if constexpr (CJ) {
                             cj_lookahead(need, my_t, ray.o, ray.d, ray.t_exit, ahead);
+                        } else if (flags & F_CONE) {
+#pragma unroll
+                            for (int j = 0; j < J; ++j)
+                                ahead[j] = ahead_cone_wave(g, fp, need[j], my_pos[j], ray.d, ray.t_exit, lane, fp.cone_cos[lane & 7u] * 0.2f, fp.cone_sin[lane & 7u] * 0.2f);
                         } else {
+                            // (the straight look-ahead through the job ring was measured: 104 us against 66 -- one chain is one lane's work
+                            // here, eight lanes' there, and the ring is a window of 32 samples)
                             bool any_need = false;
 #pragma unroll
                             for (int j = 0; j < J; ++j) any_need = any_need || need[j];
@@ -1009,8 +1020,12 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                         need[k] = chain && dense_k && ibs[k] < 255u;
                         chain = chain && dense_k == predicted;
                     }
-                    if (flags & F_CONE) {
+                    if constexpr (CJ) {
                         cj_lookahead(need, ts, ray.o, ray.d, ray.t_exit, supp);
+                    } else if (flags & F_CONE) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k)
+                            supp[k] = ahead_cone_wave(g, fp, need[k], ray.o + ray.d * ts[k], ray.d, ray.t_exit, lane, fp.cone_cos[lane & 7u] * 0.2f, fp.cone_sin[lane & 7u] * 0.2f);
                     } else {
                         bool any_need = false;
 #pragma unroll
@@ -1170,7 +1185,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
       }
     }
 
-    if (IR && (flags & F_CONE)) {
+    if (CJ) {
         // out of tiles: walk the other waves' cone jobs until every wave of the workgroup is out of tiles
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (lane == 0u) atomicSub(&s_cj_ctl[2], 1u);
