@@ -242,6 +242,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     // wave serves jobs itself while it waits, and a wave that has run out of tiles serves until every wave has: no wave ever
     // waits for anything but a job that some wave -- if need be itself -- is free to run.  Same positions and f32 operations per
     // direction as ahead_cone; every wait is bounded.
+    uint32_t cj_count = 0;          // samples this wave has asked about (wave-uniform): part of a tile's counted cost
     auto cj_serve = [&]() __attribute__((always_inline)) -> bool {
         uint32_t h = 0, n = 0;
         if (lane == 0u) {
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                     if (got != 0u && atomicCAS(&s_cj_ctl[1], tl, tl + got) != tl) got = 0;
                 }
                 got = __builtin_amdgcn_readfirstlane(got);
+                cj_count += got;
                 const uint32_t first_pos = __builtin_amdgcn_readfirstlane(tl);       // (read here, where lane 0 is active)
                 if (got != 0u) {
                     const uint32_t rank = lane_rank_in_mask(m);
@@ -487,6 +489,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
 
         if (TRACE) { trace_tiles++; tm_mark = PQ_TICK(); }
         uint32_t tile_iters = 0, tile_flushes = 0, tile_trips = 0;   // deterministic cost of this tile, fed back to the scheduler
+        const uint32_t cj_at_start = cj_count;
         uint32_t trace_ray_iters = 0;                                // TRACE: iterations this lane's ray was active in
         uint32_t tclass = TILE_MARCH;
         if (culling && !dp) {
@@ -1174,10 +1177,14 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
 #ifndef VOLYM_COST_FLUSH
 #define VOLYM_COST_FLUSH 2u
 #endif
+#ifndef VOLYM_COST_CJ
+#define VOLYM_COST_CJ 14u
+#endif
 #ifndef VOLYM_COST_FLUSH_DP
 #define VOLYM_COST_FLUSH_DP 2u
 #endif
         entry_cost += dp ? tile_iters * 10u + tile_flushes * VOLYM_COST_FLUSH_DP + tile_trips / 7u : 5u + tile_iters * 5u + tile_flushes * VOLYM_COST_FLUSH + tile_trips / 7u;
+        if (CJ) entry_cost += (cj_count - cj_at_start) * VOLYM_COST_CJ / 8u;        // a cone job of 8 samples is ~14 units of whichever wave walks it
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
