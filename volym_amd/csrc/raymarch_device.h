@@ -379,7 +379,7 @@ __device__ __forceinline__ bool probe_may_hit(const FrameParams& fp, V3 p)
 // fetches.  Every lane of the wave must call this.
 template <int K, class G>
 __device__ __forceinline__ void ahead_straight_wave(const G& g, const FrameParams& fp, const bool (&need_in)[K], const float (&ts)[K], V3 o, V3 dir,
-                                                    float t_exit, uint32_t lane, uint8_t* mail, bool (&found)[K])
+                                                    float t_exit, uint32_t lane, uint8_t* mail, bool (&found)[K], uint32_t* rounds_out = nullptr)
 {
     static_assert(K <= 4, "two bits for the sample index");
     bool need[K];
@@ -402,6 +402,7 @@ __device__ __forceinline__ void ahead_straight_wave(const G& g, const FrameParam
         found[k] = false;
     }
     if (total == 0u) return;
+    if (rounds_out) *rounds_out += (total + 63u) >> 6;          // rounds of 64 chains walked (a tile's counted cost)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll

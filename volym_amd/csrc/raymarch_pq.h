@@ -243,6 +243,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     // waits for anything but a job that some wave -- if need be itself -- is free to run.  Same positions and f32 operations per
     // direction as ahead_cone; every wait is bounded.
     uint32_t cj_count = 0;          // samples this wave has asked about (wave-uniform): part of a tile's counted cost
+    uint32_t la_rounds = 0;         // rounds of 64 straight look-ahead chains this wave has walked (wave-uniform): likewise
     auto cj_serve = [&]() __attribute__((always_inline)) -> bool {
         uint32_t h = 0, n = 0;
         if (lane == 0u) {
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
 
         if (TRACE) { trace_tiles++; tm_mark = PQ_TICK(); }
         uint32_t tile_iters = 0, tile_flushes = 0, tile_trips = 0;   // deterministic cost of this tile, fed back to the scheduler
-        const uint32_t cj_at_start = cj_count;
+        const uint32_t cj_at_start = cj_count, la_at_start = la_rounds;
         uint32_t trace_ray_iters = 0;                                // TRACE: iterations this lane's ray was active in
         uint32_t tclass = TILE_MARCH;
         if (culling && !dp) {
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                             bool any_need = false;
 #pragma unroll
                             for (int j = 0; j < J; ++j) any_need = any_need || need[j];
-                            if (__ballot(any_need) != 0ull) ahead_straight_wave<J>(g, fp, need, my_t, ray.o, ray.d, ray.t_exit, lane, mail, ahead);
+                            if (__ballot(any_need) != 0ull) ahead_straight_wave<J>(g, fp, need, my_t, ray.o, ray.d, ray.t_exit, lane, mail, ahead, &la_rounds);
                         }
 #pragma unroll
                         for (int j = 0; j < J; ++j) sm |= (static_cast<uint32_t>(__ballot(need[j] && ahead[j]) >> qsh) & 15u) << (4 * j);
@@ -1033,7 +1034,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                         bool any_need = false;
 #pragma unroll
                         for (int k = 0; k < K; ++k) any_need = any_need || need[k];
-                        if (__ballot(any_need) != 0ull) ahead_straight_wave<K>(g, fp, need, ts, ray.o, ray.d, ray.t_exit, lane, mail, supp);
+                        if (__ballot(any_need) != 0ull) ahead_straight_wave<K>(g, fp, need, ts, ray.o, ray.d, ray.t_exit, lane, mail, supp, &la_rounds);
                     }
 #pragma unroll
                     for (int k = 0; k < K; ++k) supp[k] = supp[k] && need[k];
@@ -1177,6 +1178,9 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
 #ifndef VOLYM_COST_FLUSH
 #define VOLYM_COST_FLUSH 2u
 #endif
+#ifndef VOLYM_COST_LA
+#define VOLYM_COST_LA 9u
+#endif
 #ifndef VOLYM_COST_CJ
 #define VOLYM_COST_CJ 14u
 #endif
@@ -1184,6 +1188,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
 #define VOLYM_COST_FLUSH_DP 2u
 #endif
         entry_cost += dp ? tile_iters * 10u + tile_flushes * VOLYM_COST_FLUSH_DP + tile_trips / 7u : 5u + tile_iters * 5u + tile_flushes * VOLYM_COST_FLUSH + tile_trips / 7u;
+        if (IR) entry_cost += (la_rounds - la_at_start) * VOLYM_COST_LA;           // a round of 64 chains of N probes
         if (CJ) entry_cost += (cj_count - cj_at_start) * VOLYM_COST_CJ / 8u;        // a cone job of 8 samples is ~14 units of whichever wave walks it
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
