@@ -1178,8 +1178,11 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
 #ifndef VOLYM_COST_FLUSH
 #define VOLYM_COST_FLUSH 2u
 #endif
+// a round of 64 straight look-ahead chains in cost units: measured over bonsai / teapot at 1080p and configs[4] (1024^3 + labels at
+// 4K): 0 leaves the teapot at 111 us (77 with any weight from 3 to 36) and the bonsai at 68 (64); 9 costs configs[4] 6 % (156 us
+// against 147: its frame is bound by throughput, and every tile the extra cost pushes over the split threshold adds work)
 #ifndef VOLYM_COST_LA
-#define VOLYM_COST_LA 9u
+#define VOLYM_COST_LA 3u
 #endif
 #ifndef VOLYM_COST_CJ
 #define VOLYM_COST_CJ 14u
