@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--dp", type=int, default=None, help="VOLYM_OPT_DEPTH_PARALLEL (tuning runs; default: the library's choice)")
     ap.add_argument("--layout", type=int, default=-1, help="volume layout: -1 by size (bricks beyond 64 MiB), 0 linear, 1 4x4x4 bricks")
     ap.add_argument("--kernel", type=int, default=2,
-                    help="0 direct (BASELINE configs[1]), 1 macro-cell, 2 persistent workgroups + LDS-staged tables/distance field + shading queue (configs[2], default)")
+                    help="0 direct (BASELINE configs[1]), 1 macro-cell, 2 persistent workgroups + LDS-staged tables/distance field + shading queue (configs[2], default), 3 ray pool (DESIGN.md 4.1)")
     ap.add_argument("--virtual-ranks", type=int, default=0, help="rehearsal on one GPU: N contexts on device 0 through the native multi-GPU loop, device copies instead of RCCL")
     ap.add_argument("--no-graph", action="store_true", help="N > 1: plain enqueues instead of replaying a captured HIP graph")
     ap.add_argument("--linear", action="store_true", help="trilinear volume filter (north_star mode)")
@@ -183,7 +183,7 @@ def main():
     W, H = args.width, args.height
     exit_code = 0
     gather_check = frame_check_result = None
-    first_frame_ms = moving_view_ms = static_views_ms = None
+    first_frame_ms = moving_view_ms = static_views_ms = ray_pool_ms = None
     mg_info = None
 
     if world == 1:
@@ -233,6 +233,13 @@ def main():
                 ctx.throttle(3)
             ctx.sync()
             moving_view_ms = (time.perf_counter() - t1) / n_tt * 1e3
+            # the other march kernel on the same view (VOLYM_OPT_KERNEL = 3, the ray pool of DESIGN.md 4.1: no work list, no feedback): an A/B
+            # number beside the headline, not part of it
+            ctx.set_option(_lib.OPT_KERNEL, 3)
+            ctx.update(state.camera_uniforms(), state.parameter_uniforms())
+            ctx.time_batch(20)
+            ray_pool_ms = ctx.time_batch(100) / 100
+            ctx.set_option(_lib.OPT_KERNEL, 2)
             ctx.update(state.camera_uniforms(), state.parameter_uniforms())   # back to the bench view for what follows
             for _ in range(2):
                 ctx.time_batch(3)
@@ -393,7 +400,8 @@ def main():
                 "workload": ("teapot 256x256x178->256^3" if args.teapot else "bonsai %d^3" % args.volume) + " uint8 @ %dx%d, %s filter, step %g, thr 0.15, opacity on%s, kernel=%s (BASELINE configs[%d])"
                             % (W, H, "linear" if args.linear else "nearest (reference parity)", args.step,
                                (", importance look-ahead %s" % ("cone" if args.cone else "straight") if args.importance else "") + (", gaussian smoothing" if args.gaussian else ""),
-                               {0: "direct", 1: "macro-cell", 2: "persistent workgroups, TF tables + distance field in LDS, shading queue, wave-ballot exit"}[args.kernel], 1 if args.kernel == 0 else 2),
+                               {0: "direct", 1: "macro-cell", 2: "persistent workgroups, TF tables + distance field in LDS, shading queue, wave-ballot exit",
+                                3: "ray pool: ray state and phase lists in LDS, pixel-block lattice dealing"}[args.kernel], 1 if args.kernel == 0 else 2),
                 "viewport": [W, H], "volume": list(dims), "tile_sharding": "interleaved 16x16 tiles, k %% %d" % world,
                 "virtual_ranks": (world if (procs == 1 and world > 1) else None),
                 "gather": mg_info,
@@ -403,6 +411,7 @@ def main():
             "first_frame_ms": first_frame_ms,
             "moving_view_ms": moving_view_ms,
             "static_views_ms": static_views_ms,
+            "ray_pool_ms": ray_pool_ms,
             "moving_view": (None if moving_view_ms is None else "turntable of the orbit camera, %d views %.2f degrees apart, one update + compute pass each, back to back with at most 3 frames in flight (wall clock); static_views_ms = steady state of 8 of those views" % (args.turntable_frames, args.turntable_degrees)),
             "achieved_gbs": frame_bytes * args.steps / dt / 1e9,
             "b_alg_bytes_per_frame": frame_bytes,
@@ -410,7 +419,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": pq_kernel_name if args.kernel == 2 else "volym_raymarch_kernel<%d,false,false>" % args.kernel,
+                "kernel": pq_kernel_name if args.kernel == 2 else "volym_raymarch_pool_kernel<false>" if args.kernel == 3 else "volym_raymarch_kernel<%d,false,false>" % args.kernel,
                 "kernel_avg_ms": kernel_ms, "launch_algorithmic_bytes": local_bytes,
                 "note": "algorithmic bytes = reference fetch count (n_vol*%d + n_imp) + 4 B/pixel of %s; the 32 MiB working set is "
                         "Infinity-Cache resident, so HBM traffic << algorithmic bytes (DESIGN.md)" % (b_vol, "this rank's launch" if world > 1 else "the launch"),

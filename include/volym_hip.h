@@ -59,7 +59,12 @@ enum {
                                  1 = macro-cell march: empty-space fetches elided, step
                                      arithmetic replayed exactly,
                                  2 = (default) 1 + persistent workgroups, centre-first tile
-                                     order, per-wave shading queue, speculative sample batches */
+                                     order, per-wave shading queue, speculative sample batches,
+                                 3 = ray pool (round 3): ray state in LDS, phase lists, pixel-block
+                                     lattice dealing, no work list and no cost feedback; the common
+                                     flag set only (nearest filter, opacity on, no importance mode --
+                                     every other frame runs kernel 2); same pixels as 2, ~3x slower at
+                                     1920x1080 */
     VOLYM_OPT_WRITE_F32 = 2,  /* 1 = also store pre-quantisation float RGBA (parity tests) */
     VOLYM_OPT_MACRO_CELLS = 3, /* macro cells per axis (power of two, 4..64; default 32)    */
     VOLYM_OPT_VOLUME_LAYOUT = 4, /* device layout of the NEXT volume / importance upload: -1 = by size (default: 4x4x4

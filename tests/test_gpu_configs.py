@@ -136,6 +136,79 @@ def test_timed_path_bench_workload(oracle, volym_lib):
     _u8_close(last[rows], ref_u8[rows], "bench workload, steady-state frame")
 
 
+def test_ray_pool_and_fine_cells_on_the_bench_workload(oracle, volym_lib):
+    """Round 3's selectable pieces on the bench frame (bonsai 256^3 @ 1920x1080): VOLYM_OPT_KERNEL = 3 (the ray pool: lattice dealing,
+    phase lists in LDS, 1/2/4 lanes per ray) renders the default kernel's frame bit for bit -- first frame, frames after it, a ragged
+    size and a sharded context --, and so does the default kernel on 64^3 macro cells (distance field read from global memory)."""
+    from volym_amd import _lib, demo, scene
+    raw, labels = common.bonsai(256)
+    dims = (256, 256, 256)
+    vol = scene.prepare_volume(raw, dims, True)
+    for W, H in ((1920, 1080), (1237, 701)):
+        cam, par, cu, pu = _uniforms(oracle, W, H)
+        with demo.GpuContext(W, H, 0) as ctx:
+            ctx.set_volume(vol, dims, 0)
+            ctx.set_importances(np.zeros(256 ** 3, np.uint8), dims)
+            ctx.set_transfer_function(scene.default_lut())
+            ctx.update(cu, pu)
+            ctx.compute_pass()
+            ctx.sync()
+            ref = ctx.read_rgba8().copy()
+            ctx.set_option(_lib.OPT_KERNEL, 3)
+            ctx.update(cu, pu)
+            for i in range(4):
+                ctx.compute_pass()
+                ctx.sync()                                      # (also reads the kernel's error word: a bounded wait that ran out fails here)
+                assert np.array_equal(ctx.read_rgba8(), ref), ("ray pool", W, H, i)
+            ctx.set_shard(1, 3)                                 # tile k is ours when k % 3 == 1: the lattice skips the other ranks' pixels
+            ctx.update(cu, pu)
+            ctx.compute_pass()
+            ctx.sync()
+            shard_pool = ctx.read_shard().copy()
+            ctx.set_option(_lib.OPT_KERNEL, 2)
+            ctx.update(cu, pu)
+            ctx.compute_pass()
+            ctx.sync()
+            assert np.array_equal(ctx.read_shard(), shard_pool), ("ray pool, shard", W, H)
+            ctx.set_shard(0, 1)
+            ctx.set_option(_lib.OPT_MACRO_CELLS, 64)
+            ctx.update(cu, pu)
+            ctx.compute_pass()
+            ctx.sync()
+            assert np.array_equal(ctx.read_rgba8(), ref), ("64^3 cells", W, H)
+            ctx.settle()
+            ctx.compute_pass()
+            ctx.sync()
+            assert np.array_equal(ctx.read_rgba8(), ref), ("64^3 cells, dealt list", W, H)
+
+
+def test_cone_jobs_1080p(oracle, volym_lib):
+    """The cone look-ahead as jobs shared by the waves of a workgroup (raymarch_pq.h CJ) at the size it was built for: teapot with the
+    lobster important, 1920x1080, 15 probes -- every 27th row against the oracle, frames of the dealt lists equal to the first."""
+    from volym_amd import demo, scene, synth
+    raw, labels = common.teapot()
+    dims = (256, 256, 256)
+    W, H = 1920, 1080
+    cam, par, cu, pu = _uniforms(oracle, W, H, use_importance_rendering=1, use_cone_importance_check=1)
+    vol_o, imp_o = common.oracle_scene(oracle, raw, labels, synth.TEAPOT_SEGMENTS, dims)
+    rows = list(range(5, H, 27))
+    _, ref_u8, _ = oracle.render(vol_o, imp_o, dims, oracle.tf_default_lut(), cam, par, W, H, rowlist=rows, want_f32=False)
+    with demo.GpuContext(W, H, 0) as ctx:
+        ctx.set_volume(scene.prepare_volume(raw, dims, True), dims, 0)
+        ctx.set_importances(scene.prepare_volume(scene.map_segments_to_importance(labels, synth.TEAPOT_SEGMENTS), dims, True), dims)
+        ctx.set_transfer_function(scene.default_lut())
+        ctx.update(cu, pu)
+        ctx.compute_pass()
+        ctx.sync()
+        first = ctx.read_rgba8().copy()
+        _u8_close(first[rows], ref_u8[rows], "cone jobs, first frame")
+        ctx.settle()
+        for _ in range(3):
+            ctx.compute_pass()
+        ctx.sync()
+        assert np.array_equal(ctx.read_rgba8(), first)
+
+
 def test_config3_4k(oracle, volym_lib):
     """BASELINE configs[3]: bonsai 256^3 @ 3840x2160.  One context: floats of 68 sampled rows against the oracle and the
     counters of the full frame; the steady-state frame without the float buffer equal to it; 8 virtual ranks through
