@@ -30,9 +30,9 @@ with demo.GpuContext(W, H, 0) as ctx:
     ctx.set_importances(imp, dims)
     ctx.set_transfer_function(scene.default_lut())
     import ctypes as C
-    for waves in ((0, 12, 16) if DEV else (0,)):
+    for waves in ((0, 100) if DEV else (0,)):       # 100: the straight look-ahead as shared jobs (option 121)
         if DEV:
-            ctx.set_option(115, waves)
+            ctx.set_option(121, 1 if waves == 100 else 0)
             ctx.set_option(110, 512 if os.environ.get('CJ_DEBUG') else 0)
             L = _lib.lib()
             L.volym_dev_counters.restype = C.c_int

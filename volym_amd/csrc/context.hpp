@@ -164,6 +164,7 @@ struct volym_ctx {
     uint32_t wgs_per_cu = 1;
     int kspec = 4;
     bool culling = true;
+    bool straight_jobs = false;                 // dev switch (option 121): CJ = 2 instantiation for the straight look-ahead
     bool hull_dirty = true;
     volym_camera_uniforms cam_copy;
     volym_parameter_uniforms par_copy;

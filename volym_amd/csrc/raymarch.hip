@@ -935,6 +935,9 @@ int volym_set_option(volym_ctx* c, int key, int value)
     case 118:   // drop the tiles of >= value/10 x the fair share from the lists (the frame is then incomplete): how much do they cost?
         c->dev_drop_tenths = static_cast<uint32_t>(std::max(value, 0));
         return forget_costs(c);
+    case 121:   // 1: the straight look-ahead as jobs shared by the workgroup (raymarch_pq.h CJ = 2)
+        c->straight_jobs = value != 0;
+        return VOLYM_OK;
     case 117:   // 0: no per-view tile mask (the hulls and the AABB clip stay); 2: a mask for every view, on its first frame
         c->tile_mask = value != 0;
         c->mask_eager = value == 2;
@@ -1281,7 +1284,7 @@ static int launch_march(volym_ctx* c)
 #define VOLYM_PQ_LAUNCH_J(T, KS, I, B, R, WV, J)                                                                                 \
     hipLaunchKernelGGL((volym_raymarch_pq_kernel<T, COUNT && I, TRACE, KS, I, B, R, WV, J>), dim3(pgrid), dim3(WV * 64), 0, c->stream, c->d_vol,  \
                        c->d_imp, c->d_tables, c->d_df, reinterpret_cast<const uint2*>(c->d_list[c->cur]), n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp)
-#define VOLYM_PQ_LAUNCH(T, KS, I, B, R, WV) VOLYM_PQ_LAUNCH_J(T, KS, I, B, R, WV, false)
+#define VOLYM_PQ_LAUNCH(T, KS, I, B, R, WV) VOLYM_PQ_LAUNCH_J(T, KS, I, B, R, WV, 0)
 #if VOLYM_DEV_SWITCHES
 #define VOLYM_PQ_LAUNCH_W(T, KS, I, B, R) do { if (wide12) VOLYM_PQ_LAUNCH(T, KS, I, B, R, PQ_WAVES_WIDE); else VOLYM_PQ_LAUNCH(T, KS, I, B, R, PQ_WAVES); } while (0)
 #else
@@ -1289,15 +1292,24 @@ static int launch_march(volym_ctx* c)
 #endif
         // the cone look-ahead of the importance-rendering instantiation: its walks as jobs shared by the workgroup (raymarch_pq.h CJ)
         const bool cone_jobs = ir && (fp.flags & F_CONE) != 0u && !TRACE;
+        // (dev, option 121: the straight look-ahead through the same ring, one lane per record -- measured: bonsai 79.6 us against 63.7,
+        // teapot 92.4 against 79.7: a chain of 15 probes is too little work per record to pay for the ring; not in the product library)
+        const bool straight_jobs = VOLYM_DEV_SWITCHES && ir && !(fp.flags & F_CONE) && !TRACE && c->straight_jobs;
         if (c->bricked) {
             if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, true, false, PQ_WAVES);
-            else if (table && ir && cone_jobs) VOLYM_PQ_LAUNCH_J(true, 4, false, true, true, PQ_WAVES, true);
+            else if (table && ir && cone_jobs) VOLYM_PQ_LAUNCH_J(true, 4, false, true, true, PQ_WAVES, 1);
+#if VOLYM_DEV_SWITCHES
+            else if (table && ir && straight_jobs) VOLYM_PQ_LAUNCH_J(true, 4, false, true, true, PQ_WAVES, 2);
+#endif
             else if (table && ir) { if (wide12) VOLYM_PQ_LAUNCH(true, 4, false, true, true, PQ_WAVES_WIDE); else VOLYM_PQ_LAUNCH(true, 4, false, true, true, PQ_WAVES); }
             else if (table) VOLYM_PQ_LAUNCH_W(true, 4, true, true, false);
             else VOLYM_PQ_LAUNCH_W(false, 1, true, true, false);
         } else {
             if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, false, false, PQ_WAVES);
-            else if (table && ir && cone_jobs) VOLYM_PQ_LAUNCH_J(true, 4, false, false, true, PQ_WAVES, true);
+            else if (table && ir && cone_jobs) VOLYM_PQ_LAUNCH_J(true, 4, false, false, true, PQ_WAVES, 1);
+#if VOLYM_DEV_SWITCHES
+            else if (table && ir && straight_jobs) VOLYM_PQ_LAUNCH_J(true, 4, false, false, true, PQ_WAVES, 2);
+#endif
             else if (table && ir) VOLYM_PQ_LAUNCH_W(true, 4, false, false, true);
             else if (table) VOLYM_PQ_LAUNCH_W(true, 4, true, false, false);
             else VOLYM_PQ_LAUNCH_W(false, 1, true, false, false);

@@ -115,8 +115,9 @@ __device__ __forceinline__ bool tile_mask_bit(const FrameParams& fp, uint32_t t8
 // WAVES: waves per workgroup.  16 (four per SIMD, a budget of 128 VGPRs) for the common instantiation, which fits; the
 // importance / continuous-rho instantiations need ~150 registers and run 12 waves (three per SIMD, 168 VGPRs) instead of
 // spilling 64-100 bytes per lane to scratch (profiles/r02_kernel_resources.txt).
-// CJ (with IR): the cone look-ahead's walks as jobs shared by the waves of the workgroup ("cone jobs" below)
-template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true, bool BRICK = false, bool IR = false, int WAVES = PQ_WAVES, bool CJ = false>
+// CJ (with IR): the look-ahead's walks as jobs shared by the waves of the workgroup ("cone jobs" below): 1 the cone look-ahead (a
+// record on 8 lanes, one per direction), 2 the straight look-ahead (a record on one lane)
+template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true, bool BRICK = false, bool IR = false, int WAVES = PQ_WAVES, int CJ = 0>
 __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
     const uint8_t* __restrict__ df4, const uint2* __restrict__ order, uint32_t n_items, uint16_t* __restrict__ cost,
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     constexpr int K = TABLE ? KSPEC : 2;     // speculation depth (continuous-rho modes: 2 -- each sample is 5-8 gathers)
     constexpr int PQ_QCAP = pq_qcap(K);
     static_assert(K <= 4, "the shading queue of K > 4 does not fit the LDS");
-    static_assert(!CJ || IR, "cone jobs belong to the importance-rendering instantiation");
+    static_assert(CJ == 0 || IR, "look-ahead jobs belong to the importance-rendering instantiation");
     unsigned long long trace_t0 = 0;
     uint32_t trace_iters = 0, trace_flushes = 0, trace_tiles = 0, trace_marched = 0, trace_lanes = 0, trace_accepted = 0, trace_dp_iters = 0;
     unsigned long long tm_leap = 0, tm_samp = 0, tm_flush = 0, tm_mark = 0;
@@ -147,12 +148,15 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     __shared__ uint8_t s_mail[(IMP || IR) ? WAVES : 1][(IMP || IR) ? 256 : 1];   // look-ahead candidates of a wave (ahead_straight_wave); cone jobs: the verdicts
     uint8_t (*const s_cres)[(IMP || IR) ? 256 : 1] = s_mail;      // per wave, [k][lane]: 0 pending, 1 nothing important ahead, 2 important ahead (a frame uses one of the two look-aheads)
     // IR: the cone look-ahead's walks, shared by the waves of the workgroup (below, "cone jobs")
-    constexpr uint32_t CJ_CAP = 32;      // (a window: a wave with more samples to ask about serves jobs until there is room)
+    constexpr uint32_t CJ_LPR = CJ == 2 ? 1u : 8u;                   // lanes per record
+    constexpr uint32_t CJ_RPS = 64u / CJ_LPR;                        // records per serve
+    constexpr uint32_t CJ_CAP = CJ == 2 ? 64u : 32u;      // (a window: a wave with more samples to ask about serves jobs until there is room)
+    constexpr int ITEMS_LDS = CJ == 2 ? PQ_ITEMS_LDS / 2 : PQ_ITEMS_LDS;   // (the straight jobs' ring takes the LDS of half the staged list)
     __shared__ float4 s_cj[CJ ? 2 * CJ_CAP : 1];        // {start.xyz, step} {dir.xyz, owner wave | k << 4 | lane << 6}
     __shared__ uint32_t s_cj_flag[CJ ? CJ_CAP : 1];     // 0: free, 2: being written, 1: written and not yet taken
     __shared__ uint32_t s_cj_ctl[4];                    // head, tail, waves that may still submit
     __shared__ uint32_t s_next_ticket;
-    __shared__ uint2 s_items[PQ_ITEMS_LDS];             // this workgroup's work list (entries b, b+G, ...): {item code, tile x | tile y << 16}
+    __shared__ uint2 s_items[ITEMS_LDS];                // this workgroup's work list (entries b, b+G, ...): {item code, tile x | tile y << 16}
 
     // IMP = false also pins the opacity flag of the common case so that its tests fold away; every other combination
     // runs the IMP = true instantiation
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
             for (uint32_t k = i; k < CJ_CAP; k += THREADS) s_cj_flag[k] = 0u;
             if (i == 0u) { s_cj_ctl[0] = 0u; s_cj_ctl[1] = 0u; s_cj_ctl[2] = WAVES; }
         }
-        for (uint32_t k = i; k < PQ_ITEMS_LDS; k += THREADS) {
+        for (uint32_t k = i; k < static_cast<uint32_t>(ITEMS_LDS); k += THREADS) {
             const size_t gi = blockIdx.x + static_cast<size_t>(gridDim.x) * k;
             if (gi < n_items) s_items[k] = order[gi];
         }
@@ -250,14 +254,15 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
             for (;;) {
                 h = *reinterpret_cast<volatile uint32_t*>(&s_cj_ctl[0]);
                 const uint32_t tl = *reinterpret_cast<volatile uint32_t*>(&s_cj_ctl[1]);
-                n = min(8u, tl - h);
+                n = min(CJ_RPS, tl - h);
                 if (n == 0u || atomicCAS(&s_cj_ctl[0], h, h + n) == h) break;
             }
         }
         h = __builtin_amdgcn_readfirstlane(h); n = __builtin_amdgcn_readfirstlane(n);
         if (n == 0u) return false;
         if (VOLYM_DEV_SWITCHES && (fp.dev & 512u) && lane == 0u) atomicAdd(&counters->n_imp, static_cast<unsigned long long>(n));      // debug: records taken
-        const uint32_t c = lane >> 3;
+        const uint32_t c = lane / CJ_LPR;
+        const uint32_t glead = lane & ~(CJ_LPR - 1u);                  // first lane of this record's group
         const bool job = c < n;
         const uint32_t idx = (h + c) & (CJ_CAP - 1u);
         // Take a record out of the place: 1 written -> 3 taken (exclusive: places are reserved a lap apart, two servers can be
@@ -270,18 +275,18 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
             uint32_t spins = 0;
             while (!have) {
                 uint32_t st = 0;
-                if ((lane & 7u) == 0u) st = atomicCAS(&s_cj_flag[idx], 1u, 3u) == 1u ? 1u : 0u;
-                st = __shfl(st, static_cast<int>(lane & ~7u), 64);
+                if (lane == glead) st = atomicCAS(&s_cj_flag[idx], 1u, 3u) == 1u ? 1u : 0u;
+                if (CJ_LPR > 1u) st = __shfl(st, static_cast<int>(glead), 64);
                 if (st != 0u) {
                     r0 = s_cj[2u * idx]; r1 = s_cj[2u * idx + 1u];
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    if ((lane & 7u) == 0u) *reinterpret_cast<volatile uint32_t*>(&s_cj_flag[idx]) = 0u;
+                    if (lane == glead) *reinterpret_cast<volatile uint32_t*>(&s_cj_flag[idx]) = 0u;
                     have = true; job_ok = true;
                 } else {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins >= (1u << 20)) {                 // cannot happen; never hang
                         have = true;
-                        if (VOLYM_DEV_SWITCHES && (fp.dev & 512u) && (lane & 7u) == 0u) atomicAdd(&counters->n_hit, 1ull);   // debug: a record that never came
+                        if (VOLYM_DEV_SWITCHES && (fp.dev & 512u) && lane == glead) atomicAdd(&counters->n_hit, 1ull);   // debug: a record that never came
                     }
                 }
             }
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         const uint32_t meta = __float_as_uint(r1.w);
         const int nprobe = static_cast<int>(fp.ahead_steps);
         bool hit = false;
-        {
+        if constexpr (CJ != 2) {
             const float cone_xo = fp.cone_cos[lane & 7u] * 0.2f, cone_yo = fp.cone_sin[lane & 7u] * 0.2f;
             const V3 right = normalize_exact(cross(d0, v3(0.0f, 1.0f, 0.0f)));       // wgsl:99-113, as ahead_cone
             const V3 new_up = cross(d0, right);
@@ -318,10 +323,35 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                 if (((hit_now >> (lane & 56u)) & 0xffull) != 0ull) left = true;
                 if (__ballot(!left && !hit) == 0ull) break;
             }
+        } else {
+            // the straight look-ahead (wgsl:141-160): one chain per lane, the positions the shader's accumulated additions, the bytes
+            // gathered VOLYM_PROBE_BATCH at a time and examined in order (as ahead_straight_wave walks a chain)
+            const V3 ds = d0 * step;
+            V3 pos = p0;
+            bool live = job_ok;
+            for (int i = 0; i < nprobe; i += VOLYM_PROBE_BATCH) {
+                V3 pb[VOLYM_PROBE_BATCH];
+                bool inside = false;
+#pragma unroll
+                for (int b = 0; b < VOLYM_PROBE_BATCH; ++b) {
+                    pos = pos + ds;
+                    pb[b] = pos;
+                    inside = inside || probe_may_hit(fp, pos);
+                }
+                if (__ballot(live && inside) == 0ull) continue;             // no live chain where an important texel can be read
+                uint32_t ib[VOLYM_PROBE_BATCH];
+#pragma unroll
+                for (int b = 0; b < VOLYM_PROBE_BATCH; ++b) ib[b] = imp[nearest_offset(g, pb[b])];   // clamped offset: safe wherever pos is
+#pragma unroll
+                for (int b = 0; b < VOLYM_PROBE_BATCH; ++b)
+                    if (live && i + b < nprobe && ib[b] >= 128u) { hit = true; live = false; }   // i/255 >= 0.5  <=>  i >= 128
+                if (__ballot(live) == 0ull) break;
+            }
         }
         const unsigned long long hits = __ballot(hit);
-        if (job_ok && (lane & 7u) == 0u)
-            *reinterpret_cast<volatile uint8_t*>(&s_cres[meta & 15u][((meta >> 4) & 3u) * 64u + ((meta >> 6) & 63u)]) = ((hits >> (lane & 56u)) & 0xffull) != 0ull ? 2 : 1;
+        const bool verdict = CJ == 2 ? hit : ((hits >> (lane & 56u)) & 0xffull) != 0ull;
+        if (job_ok && lane == glead)
+            *reinterpret_cast<volatile uint8_t*>(&s_cres[meta & 15u][((meta >> 4) & 3u) * 64u + ((meta >> 6) & 63u)]) = verdict ? 2 : 1;
         return true;
     };
     // the look-aheads of up to NK samples per lane (sample k at o + d * tsk[k]): submit, serve while waiting, read the verdicts.
@@ -335,7 +365,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         if (__ballot(any) == 0ull) return;
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            const bool nd = need_in[k] && !ahead_cannot_hit(fp, org + dir * tsk[k], dir, t_exit, true);   // cannot reach an important voxel: false, unwalked
+            const bool nd = need_in[k] && !ahead_cannot_hit(fp, org + dir * tsk[k], dir, t_exit, CJ == 1);   // cannot reach an important voxel: false, unwalked
             need_bits |= nd ? 1u << k : 0u;
             if (nd) *reinterpret_cast<volatile uint8_t*>(&s_cres[wave][k * 64 + lane]) = 0;
         }
@@ -414,7 +444,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         // found expensive, bit 31 | (that id << 2) | quarter: a 4x4 quarter tile marched DEPTH-PARALLEL,
         // four lanes per ray, lane k of a quad taking the k-th speculative sample (see "dp" below)
         const size_t list_pos = blockIdx.x + static_cast<size_t>(gridDim.x) * ticket;     // this entry's place in the work list
-        const uint2 entry = ticket < PQ_ITEMS_LDS ? s_items[ticket] : order[list_pos];
+        const uint2 entry = ticket < static_cast<uint32_t>(ITEMS_LDS) ? s_items[ticket] : order[list_pos];
         const uint32_t raw_p = __builtin_amdgcn_readfirstlane(entry.x);
         if (raw_p == PQ_NO_ITEM) continue;
         // the 16x16 tile's position, worked out by the host when it dealt the list (no integer division here)
@@ -771,7 +801,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                         bool need[J], ahead[J];
 #pragma unroll
                         for (int j = 0; j < J; ++j) { need[j] = active && my_b[j] >= fp.thr_byte && my_ib[j] < 255u; ahead[j] = false; }
-                        if constexpr (CJ) {
+                        if constexpr (CJ != 0) {
                             cj_lookahead(need, my_t, ray.o, ray.d, ray.t_exit, ahead);
                         } else if (flags & F_CONE) {
 #pragma unroll
@@ -1024,7 +1054,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                         need[k] = chain && dense_k && ibs[k] < 255u;
                         chain = chain && dense_k == predicted;
                     }
-                    if constexpr (CJ) {
+                    if constexpr (CJ != 0) {
                         cj_lookahead(need, ts, ray.o, ray.d, ray.t_exit, supp);
                     } else if (flags & F_CONE) {
 #pragma unroll
@@ -1192,7 +1222,8 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
 #endif
         entry_cost += dp ? tile_iters * 10u + tile_flushes * VOLYM_COST_FLUSH_DP + tile_trips / 7u : 5u + tile_iters * 5u + tile_flushes * VOLYM_COST_FLUSH + tile_trips / 7u;
         if (IR) entry_cost += (la_rounds - la_at_start) * VOLYM_COST_LA;           // a round of 64 chains of N probes
-        if (CJ) entry_cost += (cj_count - cj_at_start) * VOLYM_COST_CJ / 8u;        // a cone job of 8 samples is ~14 units of whichever wave walks it
+        if (CJ == 1) entry_cost += (cj_count - cj_at_start) * VOLYM_COST_CJ / 8u;   // a cone job of 8 samples is ~14 units of whichever wave walks it
+        if (CJ == 2) entry_cost += (cj_count - cj_at_start) * VOLYM_COST_LA / 64u;  // 64 chains: one round
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
