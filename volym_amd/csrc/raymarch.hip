@@ -1295,6 +1295,7 @@ static int launch_march(volym_ctx* c)
         // (dev, option 121: the straight look-ahead through the same ring, one lane per record -- measured: bonsai 79.6 us against 63.7,
         // teapot 92.4 against 79.7: a chain of 15 probes is too little work per record to pay for the ring; not in the product library)
         const bool straight_jobs = VOLYM_DEV_SWITCHES && ir && !(fp.flags & F_CONE) && !TRACE && c->straight_jobs;
+        (void)straight_jobs;
         if (c->bricked) {
             if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, true, false, PQ_WAVES);
             else if (table && ir && cone_jobs) VOLYM_PQ_LAUNCH_J(true, 4, false, true, true, PQ_WAVES, 1);
