@@ -283,14 +283,21 @@ def test_config3_4k(oracle, volym_lib):
 
 
 @pytest.fixture(scope="module")
-def bonsai1024():
+def bonsai1024(oracle):
+    """The product's input through the host shim, the oracle's through the ORACLE's own host path
+    (common.oracle_scene), as every other parity test does; the two must agree byte for byte, after which one copy
+    (2 GiB) is enough for both sides."""
     from volym_amd import scene
     raw, labels = common.bonsai(1024)
     dims = (1024, 1024, 1024)
     volume = scene.prepare_volume(raw, dims, True)
     importances = scene.prepare_volume(scene.map_segments_to_importance(labels, common.BONSAI_SEGMENTS), dims, True)
+    o_volume, o_importances = common.oracle_scene(oracle, raw, labels, common.BONSAI_SEGMENTS, dims)
+    assert np.array_equal(np.asarray(o_volume).ravel(), np.asarray(volume).ravel())
+    assert np.array_equal(np.asarray(o_importances).ravel(), np.asarray(importances).ravel())
+    del volume, importances
     common._cache.pop(("bonsai", 1024), None)                 # 2 GiB of raw input are not needed again
-    return dims, volume, importances
+    return dims, o_volume, o_importances
 
 
 def test_config4_1024cube_labels_4k(oracle, volym_lib, bonsai1024):
