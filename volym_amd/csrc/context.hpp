@@ -165,6 +165,7 @@ struct volym_ctx {
     int kspec = 4;
     bool culling = true;
     bool straight_jobs = false;                 // dev switch (option 121): CJ = 2 instantiation for the straight look-ahead
+    bool lds_bricks = false;        // dev option 122: LDS-staged bricks in the common instantiation (bricked layout)
     bool hull_dirty = true;
     volym_camera_uniforms cam_copy;
     volym_parameter_uniforms par_copy;

@@ -938,6 +938,9 @@ int volym_set_option(volym_ctx* c, int key, int value)
     case 121:   // 1: the straight look-ahead as jobs shared by the workgroup (raymarch_pq.h CJ = 2)
         c->straight_jobs = value != 0;
         return VOLYM_OK;
+    case 122:   // 1: the speculative voxel fetches of the common instantiation through LDS-staged bricks (raymarch_pq.h LB; bricked layout)
+        c->lds_bricks = value != 0;
+        return VOLYM_OK;
     case 117:   // 0: no per-view tile mask (the hulls and the AABB clip stay); 2: a mask for every view, on its first frame
         c->tile_mask = value != 0;
         c->mask_eager = value == 2;
@@ -1297,6 +1300,13 @@ static int launch_march(volym_ctx* c)
         const bool straight_jobs = VOLYM_DEV_SWITCHES && ir && !(fp.flags & F_CONE) && !TRACE && c->straight_jobs;
         (void)straight_jobs;
         if (c->bricked) {
+#if VOLYM_DEV_SWITCHES
+            // (dev, option 122: north_star's LDS-staged bricks, measured in profiles/r03_lds_bricks_ab.txt; not in the product library)
+            if (table && no_imp && c->lds_bricks && !COUNT && !TRACE)
+                hipLaunchKernelGGL((volym_raymarch_pq_kernel<true, false, false, 4, false, true, false, PQ_WAVES, 0, true>), dim3(pgrid), dim3(PQ_WAVES * 64), 0, c->stream, c->d_vol,
+                                   c->d_imp, c->d_tables, c->d_df, reinterpret_cast<const uint2*>(c->d_list[c->cur]), n_items, cost_out, c->d_shard, c->d_frame, c->d_f32, cnt, trace, fp);
+            else
+#endif
             if (table && no_imp) VOLYM_PQ_LAUNCH(true, 4, false, true, false, PQ_WAVES);
             else if (table && ir && cone_jobs) VOLYM_PQ_LAUNCH_J(true, 4, false, true, true, PQ_WAVES, 1);
 #if VOLYM_DEV_SWITCHES

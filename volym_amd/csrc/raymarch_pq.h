@@ -117,7 +117,10 @@ __device__ __forceinline__ bool tile_mask_bit(const FrameParams& fp, uint32_t t8
 // spilling 64-100 bytes per lane to scratch (profiles/r02_kernel_resources.txt).
 // CJ (with IR): the look-ahead's walks as jobs shared by the waves of the workgroup ("cone jobs" below): 1 the cone look-ahead (a
 // record on 8 lanes, one per direction), 2 the straight look-ahead (a record on one lane)
-template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true, bool BRICK = false, bool IR = false, int WAVES = PQ_WAVES, int CJ = 0>
+// LB (development build only, north_star "LDS-staged voxel bricks"): the K speculative voxel fetches of an iteration go through a
+// per-wave cache of 4x4x4 bricks in LDS, filled with one coalesced 64-byte read per brick (16 lanes x 4 bytes) -- the A/B of
+// profiles/r03_lds_bricks_ab.txt.  Bricked layout, common instantiation only.
+template <bool TABLE, bool COUNT, bool TRACE = false, int KSPEC = 1, bool IMP = true, bool BRICK = false, bool IR = false, int WAVES = PQ_WAVES, int CJ = 0, bool LB = false>
 __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     const uint8_t* __restrict__ vol, const uint8_t* __restrict__ imp, const FrameTables* __restrict__ tables,
     const uint8_t* __restrict__ df4, const uint2* __restrict__ order, uint32_t n_items, uint16_t* __restrict__ cost,
@@ -151,7 +154,10 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     constexpr uint32_t CJ_LPR = CJ == 2 ? 1u : 8u;                   // lanes per record
     constexpr uint32_t CJ_RPS = 64u / CJ_LPR;                        // records per serve
     constexpr uint32_t CJ_CAP = CJ == 2 ? 64u : 32u;      // (a window: a wave with more samples to ask about serves jobs until there is room)
-    constexpr int ITEMS_LDS = CJ == 2 ? PQ_ITEMS_LDS / 2 : PQ_ITEMS_LDS;   // (the straight jobs' ring takes the LDS of half the staged list)
+    static_assert(!LB || (TABLE && BRICK && !IMP && !IR && !COUNT && K == 4), "LDS brick staging: bricked layout, common instantiation");
+    constexpr uint32_t LB_SLOTS = 8u;                                // bricks per wave (8 x 64 B x 16 waves = 8 KB, taken from the staged work list)
+    __shared__ uint32_t s_lb[LB ? WAVES : 1][LB ? LB_SLOTS * 16u : 1u];
+    constexpr int ITEMS_LDS = LB ? PQ_ITEMS_LDS / 4 : CJ == 2 ? PQ_ITEMS_LDS / 2 : PQ_ITEMS_LDS;   // (the straight jobs' ring takes the LDS of half the staged list)
     __shared__ float4 s_cj[CJ ? 2 * CJ_CAP : 1];        // {start.xyz, step} {dir.xyz, owner wave | k << 4 | lane << 6}
     __shared__ uint32_t s_cj_flag[CJ ? CJ_CAP : 1];     // 0: free, 2: being written, 1: written and not yet taken
     __shared__ uint32_t s_cj_ctl[4];                    // head, tail, waves that may still submit
@@ -224,6 +230,9 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
     float4* const hh = s_hh[wave];
     uint8_t* const mail = s_mail[(IMP || IR) ? wave : 0];
 
+    // LB: lane s < LB_SLOTS holds the id of the brick staged in place s of this wave's cache (the volume does not change during a
+    // launch: the cache lives as long as the wave), lb_next the place the next miss looks at first
+    uint32_t lb_tag = 0xffffffffu, lb_next = 0u;
     uint32_t n_vol = 0, n_imp = 0, n_steps = 0, n_dense = 0, n_hit = 0;
     const float base = fp.base_step, min_step = fp.min_step, thr = fp.thr;
     const float mcf = static_cast<float>(fp.mc_n), inv_mc = 1.0f / mcf;
@@ -1012,7 +1021,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                     bs[k] = 0; ibs[k] = 0; rhos[k] = 0.0f; taps[k] = 1;
                     // the clamped texel selection keeps every offset inside the volume, whatever t is: the byte gathers
                     // need no guard (a finished lane re-reads its last texels; nothing uses them)
-                    if (TABLE) bs[k] = vol[offs[k]];
+                    if (TABLE && !LB) bs[k] = vol[offs[k]];
                     if (IR) ibs[k] = imp[offs[k]];
                     if (active) {
                         if (!IR && need_imp) ibs[k] = imp[offs[k]];
@@ -1027,9 +1036,74 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                 }
             }
 
+            // LB: which bricks do the K x 64 sample positions of this iteration touch?  One round per distinct brick of a sample
+            // slot: a brick already staged is a tag compare; a new one takes a place nobody referenced in this iteration and is
+            // fetched by 16 lanes (64 contiguous bytes), four bricks per load instruction, at most eight per iteration; lanes whose
+            // brick found no place gather their byte from global memory as the product kernel does.
+            uint32_t lb_slots = 0xffffffffu;                        // place of sample k in byte k (0xff: from global memory)
+            uint32_t lb_ld[2] = {0u, 0u}, lb_dst = 0xffffu;         // the dwords this lane fetched, and the places they go to
+            if constexpr (LB) {
+                const uint32_t* const vol32 = reinterpret_cast<const uint32_t*>(vol);
+                const unsigned long long act = __ballot(active);
+                uint32_t used = 0u, n_new = 0u, lb_b[2] = {0u, 0u};
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t bk = offs[k] >> 6;
+                    unsigned long long todo = act;
+                    while (todo != 0ull) {
+                        const uint32_t b = __builtin_amdgcn_readlane(bk, __builtin_ctzll(todo));
+                        const unsigned long long same = __ballot(bk == b) & todo;
+                        todo &= ~same;
+                        const uint32_t hit = static_cast<uint32_t>(__ballot(lb_tag == b)) & ((1u << LB_SLOTS) - 1u);
+                        uint32_t sl;
+                        if (hit != 0u) {
+                            sl = static_cast<uint32_t>(__builtin_ctz(hit));
+                            if (VOLYM_DEV_SWITCHES && (fp.dev & 512u) && lane == 0u) atomicAdd(&counters->n_hit, 1ull);
+                        } else {
+                            const uint32_t free_places = ~used & ((1u << LB_SLOTS) - 1u);
+                            if (free_places == 0u || n_new == 8u) {
+                                if (VOLYM_DEV_SWITCHES && (fp.dev & 512u) && lane == 0u) atomicAdd(&counters->n_dense, 1ull);
+                                continue;                                   // no place: these lanes gather
+                            }
+                            const uint32_t from_next = free_places & ~((1u << lb_next) - 1u);
+                            sl = static_cast<uint32_t>(__builtin_ctz(from_next != 0u ? from_next : free_places));
+                            lb_next = (sl + 1u) & (LB_SLOTS - 1u);
+                            if (lane == sl) lb_tag = b;
+                            if ((lane >> 4) == (n_new & 3u)) {              // the 16 lanes that fetch this brick
+                                if (n_new < 4u) { lb_b[0] = b; lb_dst = (lb_dst & 0xff00u) | sl; }
+                                else { lb_b[1] = b; lb_dst = (lb_dst & 0x00ffu) | (sl << 8); }
+                            }
+                            n_new++;
+                            if (VOLYM_DEV_SWITCHES && (fp.dev & 512u) && lane == 0u) atomicAdd(&counters->n_imp, 1ull);
+                        }
+                        used |= 1u << sl;
+                        if ((same >> lane) & 1ull) lb_slots = (lb_slots & ~(0xffu << (8 * k))) | (sl << (8 * k));
+                    }
+                }
+                if (VOLYM_DEV_SWITCHES && (fp.dev & 512u) && lane == 0u) atomicAdd(&counters->n_vol, 1ull);      // iterations
+                if ((lb_dst & 0xffu) != 0xffu) lb_ld[0] = vol32[lb_b[0] * 16u + (lane & 15u)];
+                if ((lb_dst >> 8) != 0xffu) lb_ld[1] = vol32[lb_b[1] * 16u + (lane & 15u)];
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if (active && ((lb_slots >> (8 * k)) & 0xffu) == 0xffu) bs[k] = vol[offs[k]];
+            }
+
             // table mode: shade here, while the byte gathers are in flight; the continuous-rho modes shade at the end of
             // the iteration instead, where the K densities are no longer live (their shading alone needs ~100 registers)
             if (TABLE) drain();
+            if constexpr (LB) {
+                // the fetched bricks into their places, then every staged sample's byte out of them (one wave: LDS accesses of a
+                // wave complete in order)
+                uint32_t* const lbw = s_lb[wave];
+                if ((lb_dst & 0xffu) != 0xffu) lbw[(lb_dst & 0xffu) * 16u + (lane & 15u)] = lb_ld[0];
+                if ((lb_dst >> 8) != 0xffu) lbw[(lb_dst >> 8) * 16u + (lane & 15u)] = lb_ld[1];
+                const uint8_t* const lbb = reinterpret_cast<const uint8_t*>(lbw);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t sl = (lb_slots >> (8 * k)) & 0xffu;
+                    if (sl != 0xffu) bs[k] = lbb[sl * 64u + (offs[k] & 63u)];
+                }
+            }
 
             // ---- 3. accept samples in order with their real classes ----
             if constexpr (TABLE && !COUNT && !IMP) {
