@@ -1399,7 +1399,13 @@ int volym_throttle(volym_ctx* c, uint32_t max_in_flight)
     // is never the slot recorded by this call, and the slot recorded here was last recorded 9 calls ago -- an earlier call has
     // already waited for a later mark than that one (marks complete in stream order).
     const uint32_t slot = c->throttle_head % volym_ctx::THROTTLE_RING;
-    if (!c->throttle_ev[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->throttle_ev[slot], hipEventDisableTiming));
+    // a pacing mark: nothing is read on the strength of it, so no system-scope fence (cache write-back and invalidation) between
+    // two frames -- with the default event the marches of a paced loop ran 6 us apart (scripts/turntable_trace.py)
+    if (!c->throttle_ev[slot] && hipEventCreateWithFlags(&c->throttle_ev[slot], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
+        (void)hipGetLastError();
+        c->throttle_ev[slot] = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&c->throttle_ev[slot], hipEventDisableTiming));
+    }
     HIPCHK(c, hipEventRecord(c->throttle_ev[slot], c->stream));
     c->throttle_head++;
     if (c->throttle_head > max_in_flight) {
