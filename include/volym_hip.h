@@ -66,7 +66,7 @@ enum {
                                      every other frame runs kernel 2); same pixels as 2, ~3x slower at
                                      1920x1080 */
     VOLYM_OPT_WRITE_F32 = 2,  /* 1 = also store pre-quantisation float RGBA (parity tests) */
-    VOLYM_OPT_MACRO_CELLS = 3, /* macro cells per axis (power of two, 4..64; default 32)    */
+    VOLYM_OPT_MACRO_CELLS = 3, /* macro cells per axis (power of two, 4..32; default 32)    */
     VOLYM_OPT_VOLUME_LAYOUT = 4, /* device layout of the NEXT volume / importance upload: -1 = by size (default: 4x4x4
                                     bricks above 64 MiB), 0 = linear, 1 = bricks.  Invisible at this boundary. */
     VOLYM_OPT_CULLING = 5,     /* 0 = no exact culling (projected hulls, AABB clip, per-view tile mask of the occupied cells) in

@@ -869,8 +869,9 @@ int volym_set_option(volym_ctx* c, int key, int value)
         }
         return VOLYM_OK;
     case VOLYM_OPT_MACRO_CELLS:
-        if (value < 4 || value > 64 || (value & (value - 1)) != 0)
-            return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_MACRO_CELLS: power of two in 4..64");
+        // (64: the development build only -- a field that does not fit the LDS, measured slower; VOLYM_DF_IN_LDS)
+        if (value < 4 || value > (VOLYM_DEV_SWITCHES ? 64 : 32) || (value & (value - 1)) != 0)
+            return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_MACRO_CELLS: power of two in 4..32");
         c->mc_n = static_cast<uint32_t>(value);
         if (c->have_vol) { int rc = build_macro_cells(c); if (rc != VOLYM_OK) return rc; }
         return forget_costs(c);

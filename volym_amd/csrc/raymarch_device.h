@@ -70,6 +70,10 @@ struct FrameParams {
 #ifndef VOLYM_DEV_SWITCHES
 #define VOLYM_DEV_SWITCHES 0     // make DEV=1 compiles the FrameParams::dev timing experiments in (scripts/ablate.py --dev)
 #endif
+// The distance field is read from LDS: 32^3 cells of 4 bits are the 16 KB it has there.  A finer grid (64^3, read from global memory
+// through L1 / L2) was measured slower and exists in the development build only: in the product kernels the test
+// folds away (it cost the common instantiation 2 % as a run-time branch in the leap look-up).
+#define VOLYM_DF_IN_LDS(fp) (!VOLYM_DEV_SWITCHES || (fp).mc_n <= 32u)
 
 enum : uint32_t {
     CULL_CUBE_HULL = 1u << 0,   // hull[0] is usable (every cube corner in front of the eye)

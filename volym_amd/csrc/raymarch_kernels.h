@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
         if (!m.table_mode) s_lut[i] = tables->lut_f[i];
         if (flags & F_IMP_COLORING) s_ic_alpha[i] = tables->ic_alpha[i];
         if (use_df) {
-            const uint32_t n16 = fp.mc_n <= 32u ? (fp.mc_n * fp.mc_n * fp.mc_n / 2u + 15u) / 16u : 0u;   // 16-byte pieces (a finer grid stays in global memory)
+            const uint32_t n16 = VOLYM_DF_IN_LDS(fp) ? (fp.mc_n * fp.mc_n * fp.mc_n / 2u + 15u) / 16u : 0u;   // 16-byte pieces (a finer grid stays in global memory)
             const uint4* src = reinterpret_cast<const uint4*>(df4);
             uint4* dst = reinterpret_cast<uint4*>(s_df);
             for (uint32_t k = i; k < n16; k += 256u) dst[k] = src[k];
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void volym_raymarch_kernel(
                     uint32_t D = 0;
                     if (static_cast<uint32_t>(cx | cy | cz) < fp.mc_n) {
                         const uint32_t ci = static_cast<uint32_t>(cx) + fp.mc_n * (static_cast<uint32_t>(cy) + fp.mc_n * static_cast<uint32_t>(cz));
-                        D = (static_cast<uint32_t>(fp.mc_n <= 32u ? s_df[ci >> 1] : df4[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
+                        D = (static_cast<uint32_t>(VOLYM_DF_IN_LDS(fp) ? s_df[ci >> 1] : df4[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
                     }
                     if (D != 0u) {
                         // box of empty cells [c-R, c+R+1]/mc_n shrunk by eps on every face, R = D-1

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(PL_WAVES * 64) void volym_raymarch_pool_kernel(
     {
         const uint32_t i = threadIdx.x;
         if (i < 256u) s_tf[i] = tables->tf_tab[i];
-        const uint32_t n16 = fp.mc_n <= 32u ? (fp.mc_n * fp.mc_n * fp.mc_n / 2u + 15u) / 16u : 0u;      // a finer grid is read from global memory (L1 / L2)
+        const uint32_t n16 = VOLYM_DF_IN_LDS(fp) ? (fp.mc_n * fp.mc_n * fp.mc_n / 2u + 15u) / 16u : 0u;      // a finer grid is read from global memory (L1 / L2)
         const uint4* src = reinterpret_cast<const uint4*>(df4);
         uint4* dst = reinterpret_cast<uint4*>(s_df);
         for (uint32_t k = i; k < n16; k += THREADS) dst[k] = src[k];
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(PL_WAVES * 64) void volym_raymarch_pool_kernel(
                 const int cx = static_cast<int>(cxf), cy = static_cast<int>(cyf), cz = static_cast<int>(czf);
                 const bool in_range = static_cast<uint32_t>(cx | cy | cz) < fp.mc_n;
                 const uint32_t ci = in_range ? mad_u24(mad_u24(static_cast<uint32_t>(cz), fp.mc_n, static_cast<uint32_t>(cy)), fp.mc_n, static_cast<uint32_t>(cx)) : 0u;
-                uint32_t D = (static_cast<uint32_t>(fp.mc_n <= 32u ? s_df[ci >> 1] : df4[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
+                uint32_t D = (static_cast<uint32_t>(VOLYM_DF_IN_LDS(fp) ? s_df[ci >> 1] : df4[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
                 if (!(want && in_range)) D = 0u;
                 if (D >= PQ_MIN_LEAP_D) {
                     const float eps = 4.0e-5f;

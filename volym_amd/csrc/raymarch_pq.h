@@ -205,7 +205,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
             if (!TABLE) s_lut[i] = tables->lut_f[i];
         }
         {
-            const uint32_t n16 = fp.mc_n <= 32u ? (fp.mc_n * fp.mc_n * fp.mc_n / 2u + 15u) / 16u : 0u;      // a finer grid is read from global memory (L1 / L2)
+            const uint32_t n16 = VOLYM_DF_IN_LDS(fp) ? (fp.mc_n * fp.mc_n * fp.mc_n / 2u + 15u) / 16u : 0u;      // a finer grid is read from global memory (L1 / L2)
             const uint4* src = reinterpret_cast<const uint4*>(df4);
             uint4* dst = reinterpret_cast<uint4*>(s_df);
             if (!(VOLYM_DEV_SWITCHES && (fp.dev & 8u)))
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
                 const int cx = static_cast<int>(cxf), cy = static_cast<int>(cyf), cz = static_cast<int>(czf);
                 const bool in_range = static_cast<uint32_t>(cx | cy | cz) < fp.mc_n;
                 const uint32_t ci = in_range ? mad_u24(mad_u24(static_cast<uint32_t>(cz), fp.mc_n, static_cast<uint32_t>(cy)), fp.mc_n, static_cast<uint32_t>(cx)) : 0u;
-                uint32_t D = (static_cast<uint32_t>(fp.mc_n <= 32u ? s_df[ci >> 1] : df4[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
+                uint32_t D = (static_cast<uint32_t>(VOLYM_DF_IN_LDS(fp) ? s_df[ci >> 1] : df4[ci >> 1]) >> ((ci & 1u) * 4u)) & 15u;
                 if (!(want_leap && in_range)) D = 0u;
                 if (D >= PQ_MIN_LEAP_D) {
                     // smoothing taps sit up to 2*0.005 along the ray from the sample (wgsl:53-60): keep them inside too
