@@ -24,6 +24,13 @@
 #include "raymarch_pool.h"
 #include "blit.h"
 
+// the common instantiation lives in raymarch_common.hip (its own scheduler flag)
+namespace volym {
+extern template __global__ void volym_raymarch_pq_kernel<true, false, false, 4, false, false, false, PQ_WAVES, 0, false>(
+    const uint8_t* __restrict__, const uint8_t* __restrict__, const FrameTables* __restrict__, const uint8_t* __restrict__, const uint2* __restrict__, uint32_t,
+    uint16_t* __restrict__, uint32_t* __restrict__, uint32_t* __restrict__, float4* __restrict__, Counters* __restrict__, uint4* __restrict__, const FrameParams);
+}  // namespace volym
+
 using namespace volym;
 
 static_assert(sizeof(volym_camera_uniforms) == 208, "CameraUniforms is 208 bytes (src/gpu_resources/camera.rs:56-64)");

@@ -74,6 +74,8 @@ struct FrameParams {
 // through L1 / L2) was measured slower and exists in the development build only: in the product kernels the test
 // folds away (it cost the common instantiation 2 % as a run-time branch in the leap look-up).
 #define VOLYM_DF_IN_LDS(fp) (!VOLYM_DEV_SWITCHES || (fp).mc_n <= 32u)
+// LDS bytes of the packed 4-bit distance field for the largest macro grid (32^3 cells)
+#define VOLYM_DF_LDS_BYTES 16384
 
 enum : uint32_t {
     CULL_CUBE_HULL = 1u << 0,   // hull[0] is usable (every cube corner in front of the eye)

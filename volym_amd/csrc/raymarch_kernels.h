@@ -108,8 +108,6 @@ __device__ __forceinline__ int dense_sample(const MarchCtx& m, const G& g, const
     return 1;
 }
 
-// LDS bytes of the packed 4-bit distance field for the largest macro grid (32^3 cells)
-#define VOLYM_DF_LDS_BYTES 16384
 
 template <int VARIANT, bool COUNT, bool TRACE, bool BRICK = false>
 __global__ __launch_bounds__(256) void volym_raymarch_kernel(
