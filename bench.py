@@ -118,6 +118,60 @@ def make_context(args, demo, _lib, W, H, device, dims, volume, importances, lut,
     return ctx
 
 
+class TorchGatherLoop:
+    """The N-process frame loop with torch.distributed carrying the packed shards -- what `--gpus N` falls back to when the native
+    loop (RCCL inside libvolym_hip.so, `volym_mgpu_*`) cannot be created on some rank.  The same protocol (volym_amd/csrc/mgpu.inc,
+    tests/test_distributed_gloo.py): a probe frame sizes the message (maximum of the stored tiles over the ranks), every frame each
+    rank marches its tiles, packs the ones that are not constant and the root gathers and assembles.  Backend "nccl" is RCCL as
+    torch loads it (device buffers); VOLYM_BENCH_FALLBACK=gloo stages through the host (the rehearsal on a one-GPU box, where RCCL
+    refuses two ranks on one device).  Frames are serialised on one stream: a fallback, not a tuned path."""
+
+    def __init__(self, ctx, torch, dist, rank, world, dev, backend):
+        self.ctx, self.torch, self.dist, self.rank, self.world, self.dev, self.backend = ctx, torch, dist, rank, world, dev, backend
+        self.group = dist.new_group(backend=backend) if backend == "nccl" else None     # gloo: the default group
+        ctx.set_shard(rank, world)
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        self.msg = 0
+
+    def update(self, cu, pu):
+        self.ctx.update(cu, pu)
+
+    def prepare(self):
+        torch, dist, ctx = self.torch, self.dist, self.ctx
+        cap = ctx.packed_shard_bytes(1 << 30)
+        probe = torch.empty(cap, dtype=torch.uint8, device=self.dev)
+        ctx.compute_pass()
+        ctx.pack_shard(probe.data_ptr(), cap)
+        used, _ = ctx.packed_tiles()
+        t = torch.tensor([used], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self.msg = ctx.packed_shard_bytes(int(t.item()))
+        self.packed = torch.zeros(self.msg, dtype=torch.uint8, device=self.dev)
+        self.gathered = torch.zeros(self.msg * self.world, dtype=torch.uint8, device=self.dev) if self.rank == 0 else None
+
+    def run(self, frames):
+        torch, dist, ctx, msg = self.torch, self.dist, self.ctx, self.msg
+        over = 0
+        for _ in range(frames):
+            ctx.compute_pass()
+            ctx.pack_shard(self.packed.data_ptr(), msg)
+            if self.backend == "nccl":
+                parts = [self.gathered[r * msg:(r + 1) * msg] for r in range(self.world)] if self.rank == 0 else None
+                dist.gather(self.packed, parts, dst=0, group=self.group)
+            else:
+                torch.cuda.current_stream(self.dev).synchronize()
+                host = self.packed.cpu()
+                parts = [torch.empty(msg, dtype=torch.uint8) for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if self.rank == 0:
+                    self.gathered.copy_(torch.cat(parts))
+            if self.rank == 0:
+                ctx.assemble_packed(self.gathered.data_ptr(), msg)
+        torch.cuda.current_stream(self.dev).synchronize()
+        over |= ctx.packed_tiles()[1]
+        return {"overflowed": over, "graph_replays": 0, "msg_bytes": msg, "enqueue_us_per_frame": None, "frames": frames, "wall_ms": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +226,8 @@ def main():
         args.gpus = procs
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if os.environ.get("VOLYM_BENCH_ONE_DEVICE") == "1":      # rehearsal of the N-process path on a one-GPU box (with VOLYM_BENCH_FALLBACK=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     world = args.virtual_ranks if (procs == 1 and args.virtual_ranks > 1) else procs    # ranks the frame is sharded over
@@ -259,65 +315,119 @@ def main():
         local = ctx
     else:
         # ---------------------------------------------- N GPUs (or N virtual ranks) ---------------------------------
+        fallback = None
         if procs > 1:
-            obj = [mgpu.unique_id() if rank == 0 else None]
+            # the native loop needs RCCL inside the library on EVERY rank: the ranks agree (gloo) before anybody enters a collective,
+            # and fall back together to torch.distributed carrying the shards (TorchGatherLoop) when one of them could not
+            mg, why = None, ""
+            forced = os.environ.get("VOLYM_BENCH_FALLBACK", "")
+            try:
+                if forced:
+                    raise RuntimeError("VOLYM_BENCH_FALLBACK=%s" % forced)
+                obj = [mgpu.unique_id() if rank == 0 else None]
+            except Exception as e:                               # librccl not loadable, no id
+                obj, why = [None], "%s: %s" % (type(e).__name__, e)
             dist.broadcast_object_list(obj, src=0)
-            mg = mgpu.MultiGpu(W, H, rank=rank, world=world, device_id=local_rank, uid=obj[0])
+            ok = torch.tensor([0 if (obj[0] is None or why) else 1], dtype=torch.int64)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                mg = mgpu.MultiGpu(W, H, rank=rank, world=world, device_id=local_rank, uid=obj[0])
+            else:
+                fb_ctx = make_context(args, demo, _lib, W, H, local_rank, dims, volume, importances, lut, state)
+                fallback = TorchGatherLoop(fb_ctx, torch, dist, rank, world, dev, "gloo" if forced == "gloo" else "nccl")
+                if rank == 0:
+                    print("bench.py: native multi-GPU loop unavailable (%s); torch.distributed (%s) carries the shards" % (why or "another rank failed", fallback.backend), file=sys.stderr)
         else:
             mg = mgpu.MultiGpu(W, H, devices=[local_rank] * world, transport=mgpu.COPY)
-        mg.set_option(_lib.OPT_KERNEL, args.kernel)
-        if args.layout >= 0:
-            mg.set_option(_lib.OPT_VOLUME_LAYOUT, args.layout)
-        mg.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
-        mg.set_importances(importances, dims)
-        mg.set_transfer_function(lut)
-        mg.update(state.camera_uniforms(), state.parameter_uniforms())
-        mg.prepare(0)                       # sizes the packed messages: one untimed frame, maximum over the ranks
-        # HIP-graph replay of the frame cycle: on for one process (virtual ranks, device copies: tested on the 1-GPU box); with one
-        # process per GPU the cycle contains grouped ncclSend/ncclRecv, and capturing those could not be rehearsed on a 1-GPU box
-        # (RCCL refuses two ranks on one device) -- plain enqueues unless VOLYM_MGPU_GRAPH=1 asks for the graph
-        use_graph = (not args.no_graph) and (procs == 1 or os.environ.get("VOLYM_MGPU_GRAPH", "0") == "1")
-        mg.run(max(args.warmup, 1), use_graph)
-        torch.cuda.synchronize(dev)
-        if procs > 1:
+        if fallback is not None:
+            fallback.update(state.camera_uniforms(), state.parameter_uniforms())
+            fallback.prepare()
+            fallback.run(max(args.warmup, 1))
             dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        try:
-            tim = mg.run(args.steps, use_graph)
-        except _lib.VolymError as e:                      # (an overflowed packed shard is an error of the run: report it, keep the ranks in step)
-            if "overflowed" not in str(e):
-                raise
-            tim = {"overflowed": 1, "graph_replays": 0, "msg_bytes": 0, "enqueue_us_per_frame": 0.0, "frames": args.steps, "wall_ms": 0.0}
-        torch.cuda.synchronize(dev)
-        if procs > 1:
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            tim = fallback.run(args.steps)
+            torch.cuda.synchronize(dev)
             dist.barrier()
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-        over = tim["overflowed"]
-        if procs > 1:
-            t = torch.tensor([dt, float(over)], dtype=torch.float64)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            t = torch.tensor([dt, float(tim["overflowed"])], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt, over = float(t[0]), int(t[1])
-        split = mg.profile(8)
-        mg_info = {"loop": "native (volym_mgpu_run): %s" % ("HIP graph, %d replays of a 4-frame cycle" % tim["graph_replays"] if tim["graph_replays"] else "plain enqueues"),
-                   "transport": "RCCL grouped ncclSend/ncclRecv to rank 0" if procs > 1 else "device copies (virtual ranks on one GPU)",
-                   "packed_bytes_per_rank_and_frame": tim["msg_bytes"], "whole_shard_bytes": mgpu_shard_bytes(W, H, world),
-                   "host_enqueue_us_per_frame": tim["enqueue_us_per_frame"], "per_stage_ms_rank0": split}
-        # untimed self-check: the gathered + assembled frame must equal the frame one context renders alone
-        if rank == 0:
-            assembled = mg.read_rgba8()
-            solo = make_context(args, demo, _lib, W, H, local_rank, dims, volume, importances, lut, state)
-            solo.compute_pass()
-            solo.sync()
-            ref = solo.read_rgba8()
-            solo.close()
-            gather_check = "ok" if np.array_equal(assembled, ref) else "MISMATCH: the assembled frame differs from the frame one context renders alone in %d bytes" % int((assembled != ref).sum())
-            if over:
-                gather_check = "OVERFLOW: a packed shard ran out of room"
-            if gather_check == "ok" and not args.no_frame_check:
-                frame_check_result = frame_check(args, dims, volume, importances, lut, state, assembled)
-        local = demo.GpuContext.borrow(mg.context_handle(0), W, H)
+            mg_info = {"loop": "fallback: Python loop, one stream, frames serialised (TorchGatherLoop)",
+                       "transport": "torch.distributed gather, backend %s" % fallback.backend,
+                       "packed_bytes_per_rank_and_frame": tim["msg_bytes"], "whole_shard_bytes": mgpu_shard_bytes(W, H, world),
+                       "host_enqueue_us_per_frame": None, "per_stage_ms_rank0": None}
+            if rank == 0:
+                assembled = fb_ctx.read_rgba8()
+            fb_ctx.set_shard(0, 1)                               # the reference frame of the self-check is the whole frame
+            fb_ctx.update(state.camera_uniforms(), state.parameter_uniforms())
+            if rank == 0:
+                fb_ctx.compute_pass()
+                fb_ctx.sync()
+                ref = fb_ctx.read_rgba8()
+                gather_check = "ok" if np.array_equal(assembled, ref) else "MISMATCH: the assembled frame differs from the frame one context renders alone in %d bytes" % int((assembled != ref).sum())
+                if over:
+                    gather_check = "OVERFLOW: a packed shard ran out of room"
+                if gather_check == "ok" and not args.no_frame_check:
+                    frame_check_result = frame_check(args, dims, volume, importances, lut, state, assembled)
+            fb_ctx.set_shard(rank, world)
+            fb_ctx.update(state.camera_uniforms(), state.parameter_uniforms())
+            local = fb_ctx
+        else:
+            mg.set_option(_lib.OPT_KERNEL, args.kernel)
+            if args.layout >= 0:
+                mg.set_option(_lib.OPT_VOLUME_LAYOUT, args.layout)
+            mg.set_volume(volume, dims, _lib.FILTER_LINEAR if args.linear else _lib.FILTER_NEAREST)
+            mg.set_importances(importances, dims)
+            mg.set_transfer_function(lut)
+            mg.update(state.camera_uniforms(), state.parameter_uniforms())
+            mg.prepare(0)                       # sizes the packed messages: one untimed frame, maximum over the ranks
+            # HIP-graph replay of the frame cycle: on for one process (virtual ranks, device copies: tested on the 1-GPU box); with one
+            # process per GPU the cycle contains grouped ncclSend/ncclRecv, and capturing those could not be rehearsed on a 1-GPU box
+            # (RCCL refuses two ranks on one device) -- plain enqueues unless VOLYM_MGPU_GRAPH=1 asks for the graph
+            use_graph = (not args.no_graph) and (procs == 1 or os.environ.get("VOLYM_MGPU_GRAPH", "0") == "1")
+            mg.run(max(args.warmup, 1), use_graph)
+            torch.cuda.synchronize(dev)
+            if procs > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            try:
+                tim = mg.run(args.steps, use_graph)
+            except _lib.VolymError as e:                      # (an overflowed packed shard is an error of the run: report it, keep the ranks in step)
+                if "overflowed" not in str(e):
+                    raise
+                tim = {"overflowed": 1, "graph_replays": 0, "msg_bytes": 0, "enqueue_us_per_frame": 0.0, "frames": args.steps, "wall_ms": 0.0}
+            torch.cuda.synchronize(dev)
+            if procs > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            over = tim["overflowed"]
+            if procs > 1:
+                t = torch.tensor([dt, float(over)], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt, over = float(t[0]), int(t[1])
+            split = mg.profile(8)
+            mg_info = {"loop": "native (volym_mgpu_run): %s" % ("HIP graph, %d replays of a 4-frame cycle" % tim["graph_replays"] if tim["graph_replays"] else "plain enqueues"),
+                       "transport": "RCCL grouped ncclSend/ncclRecv to rank 0" if procs > 1 else "device copies (virtual ranks on one GPU)",
+                       "packed_bytes_per_rank_and_frame": tim["msg_bytes"], "whole_shard_bytes": mgpu_shard_bytes(W, H, world),
+                       "host_enqueue_us_per_frame": tim["enqueue_us_per_frame"], "per_stage_ms_rank0": split}
+            # untimed self-check: the gathered + assembled frame must equal the frame one context renders alone
+            if rank == 0:
+                assembled = mg.read_rgba8()
+                solo = make_context(args, demo, _lib, W, H, local_rank, dims, volume, importances, lut, state)
+                solo.compute_pass()
+                solo.sync()
+                ref = solo.read_rgba8()
+                solo.close()
+                gather_check = "ok" if np.array_equal(assembled, ref) else "MISMATCH: the assembled frame differs from the frame one context renders alone in %d bytes" % int((assembled != ref).sum())
+                if over:
+                    gather_check = "OVERFLOW: a packed shard ran out of room"
+                if gather_check == "ok" and not args.no_frame_check:
+                    frame_check_result = frame_check(args, dims, volume, importances, lut, state, assembled)
+            local = demo.GpuContext.borrow(mg.context_handle(0), W, H)
 
     # ---- untimed self-check of the N = 1 path: the frame the timed loop left behind (a steady-state frame: cost-ordered
     # work lists, super-fill stores, no float buffer) against a fresh context's first frame (bit-equal) and against the
@@ -439,8 +549,10 @@ def main():
         exit_code = 1 if failed else 0
     if world == 1:
         ctx.close()
-    else:
+    elif mg is not None:
         mg.close()
+    else:
+        local.close()
     if procs > 1:
         code = torch.tensor([exit_code], dtype=torch.int64)
         dist.broadcast(code, src=0)
