@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from volym_amd import _lib, demo, scene, synth  # noqa: E402
 
-W, H = 1920, 1080
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 dims = (256, 256, 256)
 vol = scene.prepare_volume(synth.synth_bonsai(256), dims, True)
 L = _lib.lib()
