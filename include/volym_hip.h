@@ -75,8 +75,12 @@ enum {
     VOLYM_OPT_DEPTH_PARALLEL = 7, /* tile cost from which kernel 2 marches a tile as four depth-parallel quarter items:
                                     < 0 adaptive (-N = N/10 x a wave's fair share of the frame; -1 = default), 0 never, > 0 explicit */
     VOLYM_OPT_XCD_BANDS = 8,   /* kernels 0/1: block -> tile remap bands per XCD (0 = identity, default) */
-    VOLYM_OPT_REBALANCE_ROUNDS = 9 /* kernel 2: after a standing view's list is dealt, re-balance it this many times (0..8) from
+    VOLYM_OPT_REBALANCE_ROUNDS = 9, /* kernel 2: after a standing view's list is dealt, re-balance it this many times (0..8) from
                                     the times its workgroups took (measured: the list then depends on the weather).  Default 0. */
+    VOLYM_OPT_SETUP_IEEE = 10  /* 1 = the ray set-up (wgsl:221-241) runs its 14 divisions as 14 plain IEEE divisions; default 0: the
+                                  divisions that share a denominator share its refined reciprocal -- the same instructions on the
+                                  same values, so the same bits (raymarch_device.h make_ray; volym_selftest_ray_setup).  Takes
+                                  effect with the next volym_update. */
 };
 
 /* CameraUniforms, byte-for-byte (src/gpu_resources/camera.rs:56-64; WGSL mirror
@@ -219,6 +223,11 @@ int volym_stats_pass(volym_ctx* ctx, volym_stats* out);
 int volym_time_passes(volym_ctx* ctx, uint32_t n, float* ms_each);
 /* the same with ONE event pair around all n passes (no event packets between the kernels): total milliseconds */
 int volym_time_batch(volym_ctx* ctx, uint32_t n, float* ms_total);
+/* Self-test of the ray set-up for the frame of the last volym_update (wgsl:221-241; the reference has no counterpart): both
+ * forms of its divisions -- shared reciprocals as the march kernels run them, plain IEEE divisions as the shader writes them --
+ * for every pixel, compared bit for bit on the device.  out[0] = rays that differ in any bit of direction, entry, exit or hit
+ * (must be 0), out[1] = rays of waves that fell back to the plain divisions, out[2] = rays.  Blocks. */
+int volym_selftest_ray_setup(volym_ctx* ctx, unsigned long long out[3]);
 
 #ifdef __cplusplus
 }

@@ -888,3 +888,57 @@ int vo_blit(const uint8_t* in_rgba8, int in_w, int in_h, uint8_t* out_rgba8, int
     }
     return 0;
 }
+
+/* ---- checks of the product's ray set-up arithmetic (volym_amd/csrc/raymarch_device.h: div_pixel, rcp_refined / div_by) ----
+ * The product shares refined reciprocals between the divisions of wgsl:221-241 that have a common denominator.  These two
+ * functions restate its sequences with fmaf and compare them with this file's `/` (what vo_render uses). */
+
+/* g / W with r = RN(1 / W) and one correction, for every 0 <= g < W <= w_max: number of pairs whose bits differ from g / W */
+long vo_check_pixel_quotients(int w_max)
+{
+    long bad = 0;
+    for (int W = 1; W <= w_max; ++W) {
+        const float fw = (float)W, r = (float)(1.0 / (double)W);
+        for (int g = 0; g < W; ++g) {
+            const float a = (float)g, ref = a / fw;
+            const float q = a * r;
+            const float q1 = fmaf(fmaf(-fw, q, a), r, q);
+            if (memcmp(&q1, &ref, 4) != 0) bad++;
+        }
+    }
+    return bad;
+}
+
+/* n pseudo-random pairs with magnitudes in [2^-40, 2^40) (every 8th denominator with a significand of all ones or all ones but
+ * the last bit, every 16th a power of two): the hardware's sequence -- reciprocal estimate, two refinements, quotient, two
+ * corrections -- against num / den.  The estimate is RN(1 / den) moved by rcp_skew units in the last place (v_rcp_f32 is
+ * specified to 1 ulp).  Returns the mismatches among denominators whose significand is not 0x7fffff; *all_ones_bad counts the
+ * mismatches among those that are (with a skewed estimate the textbook exception: 1 / den just above a rounding boundary). */
+long vo_check_shared_division(uint64_t seed, long n, int rcp_skew, long* all_ones_bad)
+{
+    uint64_t s = seed ? seed : 88172645463325252ull;
+    long bad = 0, bad_ones = 0;
+    for (long i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const uint64_t x = s;
+        const uint32_t ed = 87u + (uint32_t)(x % 80u), en = 87u + (uint32_t)((x >> 8) % 80u);
+        uint32_t md = (uint32_t)(x >> 16) & 0x7fffffu;
+        const uint32_t mn = (uint32_t)(x >> 40) & 0x7fffffu;
+        if ((i & 7) == 0) md = (i & 8) ? 0x7fffffu : 0x7ffffeu;
+        if ((i & 15) == 1) md = 0u;
+        const uint32_t db = (ed << 23) | md | ((uint32_t)(x >> 63) << 31), nb = (en << 23) | mn | ((uint32_t)((x >> 62) & 1u) << 31);
+        float d, a;
+        memcpy(&d, &db, 4); memcpy(&a, &nb, 4);
+        const float ref = a / d;
+        float r = (float)(1.0 / (double)d);
+        uint32_t rb;
+        memcpy(&rb, &r, 4); rb += (uint32_t)rcp_skew; memcpy(&r, &rb, 4);
+        r = fmaf(fmaf(-d, r, 1.0f), r, r);
+        float q = a * r;
+        q = fmaf(fmaf(-d, q, a), r, q);
+        q = fmaf(fmaf(-d, q, a), r, q);
+        if (memcmp(&q, &ref, 4) != 0) { if (md == 0x7fffffu) bad_ones++; else bad++; }
+    }
+    if (all_ones_bad) *all_ones_bad = bad_ones;
+    return bad;
+}

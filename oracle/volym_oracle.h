@@ -143,6 +143,11 @@ void vo_render_pixel(const uint8_t* volume, const uint8_t* importances, int nx, 
                      const vo_camera_uniforms* cam, const vo_parameters* par,
                      int W, int H, int gx, int gy, float rgba[4], vo_counters* counters);
 
+/* Checks of the product's shared-reciprocal ray set-up (volym_amd/csrc/raymarch_device.h) against this file's divisions;
+ * tests/test_setup_division.py.  Mismatch counts: 0 is the claim. */
+long vo_check_pixel_quotients(int w_max);
+long vo_check_shared_division(uint64_t seed, long n, int rcp_skew, long* all_ones_bad);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,11 +1,13 @@
 #!/bin/bash
 # usage (GPU box, repo root; DEV build): bash scripts/pmc_ablate.sh  -- VALU instructions of the march kernel with stages deleted
 # (FrameParams::dev, scripts/ablate.py): 0 = everything, 256 = ray set-up and store only, 128 = no shading, 2 = no leaps
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_ablate
+# LIB=<file under volym_amd/> DEVS="0 256" select another development build / a subset of the switches
+LIB=${LIB:-libvolym_hip_dev.so}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_ablate_${LIB%.so}
 mkdir -p $OUT
-export VOLYM_HIP_LIB=$GRAFT_REPO_ROOT/volym_amd/libvolym_hip_dev.so
+export VOLYM_HIP_LIB=$GRAFT_REPO_ROOT/volym_amd/$LIB
 cd /tmp && export TMPDIR=/tmp
-for DEV in 0 256 128 2; do
+for DEV in ${DEVS:-0 256 128 2}; do
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $OUT/dev$DEV -- python3 $GRAFT_REPO_ROOT/scripts/ablate.py --kernels 2 --wgs 1 --cases bench --n 200 --dev $DEV > $OUT/dev$DEV.log 2>&1
   python3 - $OUT/dev$DEV $DEV <<'PY'
 import csv, glob, sys

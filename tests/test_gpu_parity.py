@@ -284,6 +284,45 @@ def test_lookahead_reject_box(oracle, volym_lib, cone):
         _check(_render_gpu(ctx, cu, par, 2), ref, "camera above, looking down, cone %d" % cone)
 
 
+def test_ray_setup_selftest(oracle, volym_lib, bonsai64):
+    """make_ray's shared reciprocals against plain divisions, bit for bit on the device, for every ray of a frame
+    (volym_selftest_ray_setup; wgsl:221-241): benchmark pose (axis-aligned: its centre row and column fall back), orbit poses,
+    the pole, a close-up from inside the volume, a ragged and a one-pixel frame, an eye on a cube face (the host does not
+    vouch: every wave falls back), and the plain-division option -- with frames equal between the two settings."""
+    from volym_amd import _lib
+    raw, labels, dims, vol, imp = bonsai64
+    par = oracle.make_parameters()
+    pu = _lib.ParameterUniforms.from_buffer_copy(bytes(par))
+    poses = [(0.0, 0.0, 0.0), (35.0, 20.0, 0.5), (-120.0, -60.0, 2.0), (90.0, 89.0, 9.0), (17.0, -33.0, -0.7), (1.0, 0.25, 0.0)]
+    for W, H in ((1920, 1080), (333, 77), (1, 1)):
+        with _ctx(W, H) as ctx:
+            _setup_ctx(ctx, raw, labels, common.BONSAI_SEGMENTS, dims, 0)
+            for pose in poses:
+                cu = _lib.CameraUniforms.from_buffer_copy(bytes(oracle.benchmark_camera_uniforms(W / H, *pose)))
+                ctx.update(cu, pu)
+                bad, fell, rays = ctx.selftest_ray_setup()
+                assert rays == W * H and bad == 0, (W, H, pose, bad, fell, rays)
+                if (W, H) == (1920, 1080):
+                    assert fell < 0.08 * rays, (pose, fell)      # rows / columns through the image centre: a direction component of 0
+                    if pose[:2] == (0.0, 0.0):
+                        assert fell > 0, pose                    # the benchmark pose is axis-aligned
+                    ctx.compute_pass(); ctx.sync()
+                    shared = ctx.read_rgba32f().copy()
+                    ctx.set_option(_lib.OPT_SETUP_IEEE, 1)
+                    ctx.update(cu, pu)
+                    b2, f2, r2 = ctx.selftest_ray_setup()
+                    assert b2 == 0 and f2 == r2 == rays
+                    ctx.compute_pass(); ctx.sync()
+                    assert np.array_equal(ctx.read_rgba32f(), shared), pose
+                    ctx.set_option(_lib.OPT_SETUP_IEEE, 0)
+            # an eye exactly on the plane x = 0 (slab numerator 0 - o.x == 0): volym_update does not vouch, all waves fall back
+            cam = oracle.camera_default(W / H, (0.0, 0.5, 3.5))
+            cu = _lib.CameraUniforms.from_buffer_copy(bytes(oracle.camera_uniforms(cam)))
+            ctx.update(cu, pu)
+            bad, fell, rays = ctx.selftest_ray_setup()
+            assert bad == 0 and fell == rays == W * H
+
+
 def test_ragged_viewport_and_tiny_volume(oracle, volym_lib):
     """Viewport not a multiple of 16 (guard wgsl:217-219), 1-voxel-thin and non-cubic volumes."""
     rng = np.random.default_rng(7)

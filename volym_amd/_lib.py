@@ -12,6 +12,7 @@ OK, E_INVALID, E_HIP, E_NO_DEVICE, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 OPT_KERNEL, OPT_WRITE_F32, OPT_MACRO_CELLS = 1, 2, 3
 OPT_VOLUME_LAYOUT, OPT_CULLING, OPT_COST_FEEDBACK, OPT_DEPTH_PARALLEL, OPT_XCD_BANDS, OPT_REBALANCE_ROUNDS = 4, 5, 6, 7, 8, 9
+OPT_SETUP_IEEE = 10
 
 
 class VolymError(RuntimeError):
@@ -148,6 +149,7 @@ SIGNATURES = {
     "volym_stats_pass": (C.c_int, [_ctx, C.POINTER(Stats)]),
     "volym_time_passes": (C.c_int, [_ctx, C.c_uint32, _f32p]),
     "volym_time_batch": (C.c_int, [_ctx, C.c_uint32, _f32p]),
+    "volym_selftest_ray_setup": (C.c_int, [_ctx, C.POINTER(C.c_ulonglong)]),
     # include/volym_host.h
     "volym_camera_default_with_aspect_and_pos": (None, [C.POINTER(CCamera), C.c_float, _f32p]),
     "volym_camera_orbit": (None, [C.POINTER(CCamera), C.c_float, C.c_float, C.c_float]),

@@ -164,6 +164,7 @@ struct volym_ctx {
     uint32_t wgs_per_cu = 1;
     int kspec = 4;
     bool culling = true;
+    bool setup_ieee = false;                    // VOLYM_OPT_SETUP_IEEE: make_ray with plain divisions (FrameParams::setup_lo = +inf)
     bool straight_jobs = false;                 // dev switch (option 121): CJ = 2 instantiation for the straight look-ahead
     bool lds_bricks = false;        // dev option 122: LDS-staged bricks in the common instantiation (bricked layout)
     bool hull_dirty = true;

@@ -901,6 +901,10 @@ int volym_set_option(volym_ctx* c, int key, int value)
         if (value < 0 || value > 8) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_REBALANCE_ROUNDS: 0..8");
         c->trim_rounds = static_cast<uint32_t>(value);
         return VOLYM_OK;
+    case VOLYM_OPT_SETUP_IEEE:
+        if (value != 0 && value != 1) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_SETUP_IEEE: 0 or 1");
+        c->setup_ieee = value == 1;       // read by the next volym_update
+        return VOLYM_OK;
     case VOLYM_OPT_XCD_BANDS:
         if (value < 0 || value > 64) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_XCD_BANDS: 0..64");
         c->xcd_bands = static_cast<uint32_t>(value);
@@ -1171,6 +1175,18 @@ int volym_update(volym_ctx* c, const volym_camera_uniforms* cam, const volym_par
                (par->use_gaussian_smoothing == 1u ? F_GAUSSIAN : 0u) | (c->filter == VOLYM_FILTER_LINEAR ? F_LINEAR : 0u);
     fp.ahead_steps = par->importance_check_ahead_steps;
     fp.W = c->W; fp.H = c->H;
+    {
+        // make_ray's shared-reciprocal divisions (raymarch_device.h): the host's part of the range argument
+        fp.rcp_w = static_cast<float>(1.0 / static_cast<double>(c->W));
+        fp.rcp_h = static_cast<float>(1.0 / static_cast<double>(c->H));
+        bool vouch = c->W <= 16384u && c->H <= 16384u && !c->setup_ieee;
+        for (int i = 0; i < 16; ++i) vouch = vouch && std::fabs(fp.ivp[i]) < 0x1p+60f;
+        for (int i = 0; i < 3; ++i) {
+            const float n0 = std::fabs(0.0f - fp.eye[i]), n1 = std::fabs(1.0f - fp.eye[i]);
+            vouch = vouch && n0 >= 0x1p-40f && n0 <= 0x1p+40f && n1 >= 0x1p-40f && n1 <= 0x1p+40f;
+        }
+        fp.setup_lo = vouch ? 0x1p-40f : INFINITY;
+    }
     fp.nx = c->nx; fp.ny = c->ny; fp.nz = c->nz;
     fp.tiles_x = c->tiles_x; fp.n_tiles = c->n_tiles;
     fp.tf_n = c->tf_n;
@@ -1617,6 +1633,26 @@ int volym_stats_pass(volym_ctx* c, volym_stats* out)
         rays += static_cast<uint64_t>(w) * h2;
     }
     out->n_rays = rays;
+    return VOLYM_OK;
+}
+
+// Both forms of the ray set-up (raymarch_device.h make_ray) for every pixel of the current frame, compared bit for bit on the
+// device.  out[0]: rays whose shared-reciprocal set-up (as the march kernels run it, fallback included) differs from the plain
+// divisions in any bit of direction / entry / exit / hit; out[1]: rays of waves that took the fallback; out[2]: rays.
+int volym_selftest_ray_setup(volym_ctx* c, unsigned long long out[3])
+{
+    if (!c || !out) return VOLYM_E_INVALID;
+    if (!c->have_frame) return fail(c, VOLYM_E_STATE, "volym_selftest_ray_setup: call volym_update first");
+    HIPCHK(c, hipSetDevice(c->device));
+    static_assert(sizeof(Counters) >= 3 * sizeof(unsigned long long), "counters");
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));
+    const dim3 grid((c->W + 63u) / 64u, (c->H + 3u) / 4u);
+    volym_ray_setup_selftest_kernel<<<grid, 256, 0, c->stream>>>(c->fp, reinterpret_cast<unsigned long long*>(c->d_counters));
+    HIPCHK(c, hipGetLastError());
+    Counters h;
+    HIPCHK(c, hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out[0] = h.n_vol; out[1] = h.n_imp; out[2] = h.n_steps;
     return VOLYM_OK;
 }
 

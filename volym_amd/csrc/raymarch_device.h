@@ -63,6 +63,8 @@ struct FrameParams {
                                  // meet anything dense
     uint32_t* tile_mask_spare;   // the mask buffer this view does not use: every launch zeroes it for the next view's mask kernel
     uint32_t mask_words;
+    float rcp_w, rcp_h;          // RN(1 / W), RN(1 / H): make_ray's pixel quotients (raymarch_device.h div_pixel)
+    float setup_lo;              // 2^-40 when make_ray may share reciprocals between its divisions, +inf when it must not (volym_update)
     uint32_t rect[4];            // variant 3: the screen rectangle {x0, y0, x1, y1} (pixels, whole 64x32 superblocks, x1/y1 may pass the frame) outside of
                                  // which no ray can meet anything dense; x1 <= x0: no such pixel at all
 };
@@ -670,14 +672,60 @@ __device__ __forceinline__ uint32_t pack_rgba8(float r, float g, float b, float 
     return to_unorm8(r) | (to_unorm8(g) << 8) | (to_unorm8(b) << 16) | (to_unorm8(a) << 24);
 }
 
+// ---- ray set-up (wgsl:221-241, EXACT) ----
+// The 14 divisions of the set-up share 5 denominators (W, H, wp.w, |world - eye|, and each direction component for its slab pair).
+// hipcc expands a binary32 division into: v_div_scale (denominator), v_div_scale (numerator), v_rcp, two fma that refine the
+// reciprocal, a multiply and three fma that form and correct the quotient twice (the last one is v_div_fmas), v_div_fixup.  When
+// both operands are normal numbers of moderate size -- here: magnitudes in (2^-40, 2^40), the exact conditions are those of
+// v_div_scale_f32 in the ISA manual: |exponent difference| < 96, neither 1/den nor num/den denormal, biased exponent(num) > 23 --
+// the two v_div_scale return their operand unchanged and clear VCC, v_div_fmas is a plain fma and v_div_fixup returns the
+// quotient it is given.  What is left are the eight instructions below, and the first three depend on the denominator only: the
+// quotients rcp_refined / div_by produce are, instruction for instruction, those of the `/` operator.  make_ray computes the set-up
+// with them speculatively, checks the ranges on the values themselves, and a wave in which any lane is outside them recomputes
+// the set-up with plain divisions (wave-uniform branch; in practice: rays exactly parallel to a cube face).
+// tests/test_setup_division.py: the sequence against IEEE division on the CPU (exhaustive for the pixel quotients);
+// volym_selftest_ray_setup + tests/test_gpu_parity.py: both forms on the device, every bit of every ray of a frame.
+__device__ __forceinline__ float rcp_refined(float d)
+{
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float div_by(float n, float d, float r)
+{
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+}
+// gx / W for integers 0 <= gx < W <= 16384 with r = RN(1 / W) from the host: one correction step gives the correctly rounded
+// quotient for every such pair (exhaustive: tests/test_setup_division.py, 134 M pairs)
+__device__ __forceinline__ float div_pixel(float g, float w, float r)
+{
+    const float q = g * r;
+    return __builtin_fmaf(__builtin_fmaf(-w, q, g), r, q);
+}
+
 struct Ray {
     V3 o, d;
     float t_entry, t_exit;
     bool hit;
 };
 
-// wgsl:221-241  (EXACT)
-__device__ __forceinline__ Ray make_ray(const FrameParams& fp, uint32_t gx, uint32_t gy)
+__device__ __forceinline__ void ray_slabs(Ray& r, float t1x, float t2x, float t1y, float t2y, float t1z, float t2z)
+{
+    const float entry = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
+                                        __builtin_fminf(t1z, t2z));
+    const float exit_ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
+                                        __builtin_fmaxf(t1z, t2z));
+    r.t_entry = __builtin_fmaxf(entry, 0.0f);
+    r.t_exit = __builtin_fmaxf(exit_, 0.0f);
+    r.hit = !(r.t_exit <= r.t_entry);
+}
+
+// the shader's arithmetic, operation for operation
+__device__ __forceinline__ Ray make_ray_ieee(const FrameParams& fp, uint32_t gx, uint32_t gy)
 {
     Ray r;
     const float scx = static_cast<float>(gx) / static_cast<float>(fp.W);
@@ -691,17 +739,52 @@ __device__ __forceinline__ Ray make_ray(const FrameParams& fp, uint32_t gx, uint
     r.o = v3(fp.eye[0], fp.eye[1], fp.eye[2]);
     const V3 world = v3(wp[0] / wp[3], wp[1] / wp[3], wp[2] / wp[3]);
     r.d = normalize_exact(world - r.o);
-    const float t1x = (0.0f - r.o.x) / r.d.x, t2x = (1.0f - r.o.x) / r.d.x;
-    const float t1y = (0.0f - r.o.y) / r.d.y, t2y = (1.0f - r.o.y) / r.d.y;
-    const float t1z = (0.0f - r.o.z) / r.d.z, t2z = (1.0f - r.o.z) / r.d.z;
-    const float entry = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
-                                        __builtin_fminf(t1z, t2z));
-    const float exit_ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
-                                        __builtin_fmaxf(t1z, t2z));
-    r.t_entry = __builtin_fmaxf(entry, 0.0f);
-    r.t_exit = __builtin_fmaxf(exit_, 0.0f);
-    r.hit = !(r.t_exit <= r.t_entry);
+    ray_slabs(r, (0.0f - r.o.x) / r.d.x, (1.0f - r.o.x) / r.d.x, (0.0f - r.o.y) / r.d.y, (1.0f - r.o.y) / r.d.y,
+              (0.0f - r.o.z) / r.d.z, (1.0f - r.o.z) / r.d.z);
     return r;
+}
+
+// the same values through shared reciprocals; ok: every operand was inside the range in which that is the same arithmetic
+__device__ __forceinline__ Ray make_ray_shared(const FrameParams& fp, uint32_t gx, uint32_t gy, bool& ok)
+{
+    Ray r;
+    const float scx = div_pixel(static_cast<float>(gx), static_cast<float>(fp.W), fp.rcp_w);
+    const float scy = div_pixel(static_cast<float>(gy), static_cast<float>(fp.H), fp.rcp_h);
+    const float ndx = scx * 2.0f - 1.0f;
+    const float ndy = 1.0f - scy * 2.0f;
+    float wp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        wp[k] = ((fp.ivp[k] * ndx + fp.ivp[4 + k] * ndy) + fp.ivp[8 + k] * 0.0f) + fp.ivp[12 + k] * 1.0f;
+    r.o = v3(fp.eye[0], fp.eye[1], fp.eye[2]);
+    const float rw = rcp_refined(wp[3]);
+    const V3 a = v3(div_by(wp[0], wp[3], rw), div_by(wp[1], wp[3], rw), div_by(wp[2], wp[3], rw)) - r.o;
+    const float len = length_exact(a);
+    const float rl = rcp_refined(len);
+    r.d = v3(div_by(a.x, len, rl), div_by(a.y, len, rl), div_by(a.z, len, rl));
+    const float rx = rcp_refined(r.d.x), ry = rcp_refined(r.d.y), rz = rcp_refined(r.d.z);
+    ray_slabs(r, div_by(0.0f - r.o.x, r.d.x, rx), div_by(1.0f - r.o.x, r.d.x, rx), div_by(0.0f - r.o.y, r.d.y, ry),
+              div_by(1.0f - r.o.y, r.d.y, ry), div_by(0.0f - r.o.z, r.d.z, rz), div_by(1.0f - r.o.z, r.d.z, rz));
+    // Ranges.  wp (4 values) and len inside (setup_lo, 2^40): setup_lo is 2^-40, or +inf when the host could not vouch for its part
+    // (W, H <= 16384; |ivp| < 2^60, so that wp is never NaN: fmin / fmax would drop one; the six slab numerators inside
+    // [2^-40, 2^40]).  Direction components above 2^-30 in magnitude: with len in range that bounds the numerators of the
+    // normalisation from below (a zero or tiny component gives a quotient below 2^-60 whatever the sequence does with it), their
+    // upper bound is len itself; and it is the range of the slab denominators.
+    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fabsf(wp[0]), __builtin_fabsf(wp[1])), __builtin_fabsf(wp[2])),
+                                     __builtin_fminf(__builtin_fabsf(wp[3]), len));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(wp[0]), __builtin_fabsf(wp[1])), __builtin_fabsf(wp[2])),
+                                     __builtin_fmaxf(__builtin_fabsf(wp[3]), len));
+    const float dlo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(r.d.x), __builtin_fabsf(r.d.y)), __builtin_fabsf(r.d.z));
+    ok = lo > fp.setup_lo && hi < 0x1p+40f && dlo > 0x1p-30f;
+    return r;
+}
+
+__device__ __forceinline__ Ray make_ray(const FrameParams& fp, uint32_t gx, uint32_t gy)
+{
+    bool ok;
+    const Ray r = make_ray_shared(fp, gx, gy, ok);
+    if (__builtin_expect(__ballot(!ok) == 0ull, 1)) return r;
+    return make_ray_ieee(fp, gx, gy);
 }
 
 }  // namespace volym

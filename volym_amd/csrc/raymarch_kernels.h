@@ -404,6 +404,30 @@ __global__ __launch_bounds__(1024) void volym_distance_field_kernel(const uint8_
 // its corners in front of the eye: CULL_OBJ_HULL); a cell with a corner that is not sets every bit.
 struct ClipMatrix { float m[16]; };   // world -> clip, column-major
 constexpr uint32_t VOLYM_TILE_MASK_MAX_WORDS = 1u << 20;     // 32 M tiles of 8x8 pixels
+// volym_selftest_ray_setup: one pixel per thread (64 x 4 pixels per workgroup, a wave = 64 pixels of a row)
+__global__ __launch_bounds__(256) void volym_ray_setup_selftest_kernel(FrameParams fp, unsigned long long* __restrict__ out)
+{
+    const uint32_t gx = blockIdx.x * 64u + (threadIdx.x & 63u), gy = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (gx >= fp.W || gy >= fp.H) return;
+    bool ok;
+    const Ray s = make_ray_shared(fp, gx, gy, ok);
+    const bool fell_back = __ballot(!ok) != 0ull;
+    const Ray p = make_ray(fp, gx, gy);               // what the march kernels call
+    const Ray q = make_ray_ieee(fp, gx, gy);
+    auto same = [](float a, float b) { return __float_as_uint(a) == __float_as_uint(b); };
+    const bool eq = same(p.d.x, q.d.x) && same(p.d.y, q.d.y) && same(p.d.z, q.d.z) && same(p.t_entry, q.t_entry) &&
+                    same(p.t_exit, q.t_exit) && p.hit == q.hit && same(p.o.x, q.o.x) && same(p.o.y, q.o.y) && same(p.o.z, q.o.z);
+    // a lane inside the ranges must agree on its own, whatever the rest of its wave did
+    const bool eq_s = !ok || (same(s.d.x, q.d.x) && same(s.d.y, q.d.y) && same(s.d.z, q.d.z) && same(s.t_entry, q.t_entry) &&
+                              same(s.t_exit, q.t_exit) && s.hit == q.hit);
+    const unsigned long long bad = __ballot(!(eq && eq_s)), all = __ballot(true);
+    if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(static_cast<long long>(all)) - 1)) {
+        if (bad) atomicAdd(&out[0], static_cast<unsigned long long>(__popcll(bad)));
+        if (fell_back) atomicAdd(&out[1], static_cast<unsigned long long>(__popcll(all)));
+        atomicAdd(&out[2], static_cast<unsigned long long>(__popcll(all)));
+    }
+}
+
 __global__ __launch_bounds__(256) void volym_tile_mask_kernel(const uint8_t* __restrict__ mc_max, uint32_t mc_n, uint32_t thr_byte, ClipMatrix M,
                                                               float margin, uint32_t W, uint32_t H, uint32_t t8x, uint32_t n_words,
                                                               uint32_t* __restrict__ out)

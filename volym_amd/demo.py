@@ -178,6 +178,12 @@ class GpuContext:
         self._ck(_lib.lib().volym_stats_pass(self.handle, C.byref(s)))
         return s.as_dict()
 
+    def selftest_ray_setup(self):
+        """(rays whose shared-reciprocal set-up differs from plain divisions, rays of waves that fell back, rays)."""
+        out = (C.c_ulonglong * 3)()
+        self._ck(_lib.lib().volym_selftest_ray_setup(self.handle, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def time_batch(self, n):
         """n back-to-back passes between one pair of HIP events: total milliseconds."""
         ms = C.c_float(0.0)
