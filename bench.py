@@ -102,8 +102,10 @@ def frame_check(args, dims, volume, importances, lut, state, got_u8, n_rows=68):
     return "MISMATCH: %d of %d sampled pixels differ from the oracle by more than 1 LSB (max %d)" % (int((d.max(axis=-1) > 1).sum()), len(rows) * W, int(d.max()))
 
 
-def make_context(args, demo, _lib, W, H, device, dims, volume, importances, lut, state):
+def make_context(args, demo, _lib, W, H, device, dims, volume, importances, lut, state, frames_in_flight=1):
     ctx = demo.GpuContext(W, H, device)
+    if frames_in_flight == 2:                       # before the scene: it goes to both frame contexts (include/volym_hip.h)
+        ctx.set_option(_lib.OPT_FRAMES_IN_FLIGHT, 2)
     ctx.set_option(_lib.OPT_KERNEL, args.kernel)
     if args.layout >= 0:
         ctx.set_option(_lib.OPT_VOLUME_LAYOUT, args.layout)
@@ -192,6 +194,10 @@ def main():
     ap.add_argument("--gaussian", action="store_true", help="use_gaussian_smoothing = 1 (the interactive default, src/state.rs:50)")
     ap.add_argument("--cone", action="store_true")
     ap.add_argument("--xcd-bands", type=int, default=-1)
+    ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=2,
+                    help="N = 1: VOLYM_OPT_FRAMES_IN_FLIGHT -- 2 (default): compute passes alternate between two frame contexts on the device "
+                         "(two streams, two frame buffers), the next frame's workgroups take the CUs the previous frame's tail leaves idle; "
+                         "1: one frame after the other.  The roofline leg always times the kernel alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-moving-view", action="store_true", help="skip the first-frame and turntable timings (N = 1)")
     ap.add_argument("--turntable-frames", type=int, default=720)
@@ -244,7 +250,7 @@ def main():
 
     if world == 1:
         # ---------------------------------------------- one GPU -----------------------------------------------------
-        ctx = make_context(args, demo, _lib, W, H, local_rank, dims, volume, importances, lut, state)
+        ctx = make_context(args, demo, _lib, W, H, local_rank, dims, volume, importances, lut, state, args.frames_in_flight)
         frame = torch.empty(W * H * 4, dtype=torch.uint8, device=dev)
         ctx.bind_output(None, frame.data_ptr())
         # ---- beside the steady state (N = 1), BEFORE the timed region (these ~50 ms of frames also bring the device to its
@@ -516,6 +522,7 @@ def main():
                 "virtual_ranks": (world if (procs == 1 and world > 1) else None),
                 "gather": mg_info,
             },
+            "frames_in_flight": (args.frames_in_flight if world == 1 else None),
             "gather_check": gather_check,
             "frame_check": frame_check_result,
             "first_frame_ms": first_frame_ms,
@@ -532,7 +539,10 @@ def main():
                 "kernel": pq_kernel_name if args.kernel == 2 else "volym_raymarch_pool_kernel<false>" if args.kernel == 3 else "volym_raymarch_kernel<%d,false,false>" % args.kernel,
                 "kernel_avg_ms": kernel_ms, "launch_algorithmic_bytes": local_bytes,
                 "note": "algorithmic bytes = reference fetch count (n_vol*%d + n_imp) + 4 B/pixel of %s; the 32 MiB working set is "
-                        "Infinity-Cache resident, so HBM traffic << algorithmic bytes (DESIGN.md)" % (b_vol, "this rank's launch" if world > 1 else "the launch"),
+                        "Infinity-Cache resident, so HBM traffic << algorithmic bytes (DESIGN.md)" % (b_vol, "this rank's launch" if world > 1 else "the launch")
+                        + ("; frac and kernel_avg_ms are the kernel's own (back-to-back launches on one stream); ms_per_step is below kernel_avg_ms because the "
+                           "timed loop keeps two frames in flight (VOLYM_OPT_FRAMES_IN_FLIGHT = 2: alternate frames on two streams, the next frame's workgroups "
+                           "fill the CUs the previous frame's tail leaves idle) -- achieved_gbs is the algorithmic-byte rate of that loop" if (world == 1 and args.frames_in_flight == 2) else ""),
             },
         }
         if not args.no_cpu_baseline and world == 1:

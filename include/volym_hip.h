@@ -77,6 +77,16 @@ enum {
     VOLYM_OPT_XCD_BANDS = 8,   /* kernels 0/1: block -> tile remap bands per XCD (0 = identity, default) */
     VOLYM_OPT_REBALANCE_ROUNDS = 9, /* kernel 2: after a standing view's list is dealt, re-balance it this many times (0..8) from
                                     the times its workgroups took (measured: the list then depends on the weather).  Default 0. */
+    VOLYM_OPT_FRAMES_IN_FLIGHT = 11, /* 1 (default) = one frame after the other on the context's stream.  2 = the context keeps a
+                                  second complete context on the same device (stream, frame buffer, copy of the volume, lists,
+                                  feedback) and volym_compute_pass alternates between the two: a frame of the persistent kernel
+                                  ends on its longest chains, and the next frame's workgroups take the CUs it leaves idle
+                                  (1920x1080: 31.9 -> 27.6 us per frame; 3840x2160: 74.7 -> 70.7).  Set it before the volume,
+                                  the importances and the transfer function (they go to both), and not with a caller's stream.
+                                  volym_update / _settle / _sync / _set_* act on both; volym_read_rgba8 / _rgba32f / volym_blit
+                                  take the frame of the latest pass; volym_throttle marks it; volym_stats_pass, volym_time_*
+                                  and volym_selftest_ray_setup use the first context alone (one frame at a time); the shard /
+                                  pack / assemble calls and volym_set_stream return VOLYM_E_STATE.  Memory: everything twice. */
     VOLYM_OPT_SETUP_IEEE = 10  /* 1 = the ray set-up (wgsl:221-241) runs its 14 divisions as 14 plain IEEE divisions; default 0: the
                                   divisions that share a denominator share its refined reciprocal -- the same instructions on the
                                   same values, so the same bits (raymarch_device.h make_ray; volym_selftest_ray_setup).  Takes

@@ -323,6 +323,68 @@ def test_ray_setup_selftest(oracle, volym_lib, bonsai64):
             assert bad == 0 and fell == rays == W * H
 
 
+def test_frames_in_flight(oracle, volym_lib, bonsai64):
+    """VOLYM_OPT_FRAMES_IN_FLIGHT = 2: compute passes alternate between the context and its twin (own stream and frame buffer).
+    Every frame of a sequence of views -- i.e. frames of BOTH contexts -- against the oracle (floats, rgba8, and the blit of the
+    latest frame), frames enqueued back to back without a sync in between, standing views through settle, the calls that are
+    refused, and the way back to one frame at a time."""
+    from volym_amd import _lib
+    raw, labels, dims, vol, imp = bonsai64
+    W, H = 200, 120
+    lut = oracle.tf_default_lut()
+    poses = [(0.0, 0.0, 0.0), (35.0, 20.0, 0.5), (-120.0, -60.0, 2.0), (90.0, 89.0, 9.0), (17.0, -33.0, -0.7)]
+    pars = [oracle.make_parameters(), oracle.make_parameters(use_importance_rendering=1),
+            oracle.make_parameters(use_gaussian_smoothing=1, density_threshold=0.12)]
+    with _ctx(W, H) as ctx:
+        ctx.set_option(_lib.OPT_FRAMES_IN_FLIGHT, 2)
+        _setup_ctx(ctx, raw, labels, common.BONSAI_SEGMENTS, dims, 0)
+        n = 0
+        for par in pars:
+            pu = _lib.ParameterUniforms.from_buffer_copy(bytes(par))
+            for pose in poses:                       # 5 views per parameter set: the parity of the frame counter keeps changing sides
+                cam = oracle.benchmark_camera_uniforms(W / H, *pose)
+                ref = oracle.render(vol, imp, dims, lut, cam, par, W, H)
+                ctx.update(_lib.CameraUniforms.from_buffer_copy(bytes(cam)), pu)
+                ctx.compute_pass()
+                ctx.blit(W, H)
+                ctx.sync()
+                gf, gu = ctx.read_rgba32f(), ctx.read_rgba8()
+                err, over, du8, _ = common.compare_images(gf, gu, ref[0], ref[1], TOL)
+                assert over == 0 and err <= TOL and du8 <= 1, (n, pose, err, over, du8)
+                assert np.array_equal(ctx.read_blit(), gu), (n, pose)
+                n += 1
+        # a standing view: frames back to back on both streams, settled lists, then the two latest frames
+        cam = oracle.benchmark_camera_uniforms(W / H, 35.0, 20.0, 0.5)
+        par = pars[0]
+        ref = oracle.render(vol, imp, dims, lut, cam, par, W, H)
+        ctx.update(_lib.CameraUniforms.from_buffer_copy(bytes(cam)), _lib.ParameterUniforms.from_buffer_copy(bytes(par)))
+        for _ in range(3):
+            for _ in range(40):
+                ctx.compute_pass()
+                ctx.throttle(3)
+            ctx.settle()
+        for k in range(2):                          # one more frame each: the latest frame comes from either context in turn
+            ctx.compute_pass()
+            ctx.sync()
+            err, over, du8, _ = common.compare_images(ctx.read_rgba32f(), ctx.read_rgba8(), ref[0], ref[1], TOL)
+            assert over == 0 and err <= TOL and du8 <= 1, (k, err, over, du8)
+        stats = ctx.stats_pass()                    # the first context alone
+        for key in ("n_vol", "n_imp", "n_steps", "n_dense", "n_hit"):
+            assert stats[key] == ref[2][key], key
+        for call in (lambda: ctx.set_stream(0), lambda: ctx.pack_shard(0, 0), lambda: ctx.read_shard()):
+            with pytest.raises(_lib.VolymError) as e:
+                call()
+            assert e.value.code == _lib.E_STATE
+        ctx.set_option(_lib.OPT_FRAMES_IN_FLIGHT, 1)
+        ctx.compute_pass()
+        ctx.sync()
+        err, over, du8, _ = common.compare_images(ctx.read_rgba32f(), ctx.read_rgba8(), ref[0], ref[1], TOL)
+        assert over == 0 and err <= TOL and du8 <= 1
+        with pytest.raises(_lib.VolymError) as e:   # a twin needs the scene from the start
+            ctx.set_option(_lib.OPT_FRAMES_IN_FLIGHT, 2)
+        assert e.value.code == _lib.E_STATE
+
+
 def test_ragged_viewport_and_tiny_volume(oracle, volym_lib):
     """Viewport not a multiple of 16 (guard wgsl:217-219), 1-voxel-thin and non-cubic volumes."""
     rng = np.random.default_rng(7)

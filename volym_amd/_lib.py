@@ -13,6 +13,7 @@ FILTER_NEAREST, FILTER_LINEAR = 0, 1
 OPT_KERNEL, OPT_WRITE_F32, OPT_MACRO_CELLS = 1, 2, 3
 OPT_VOLUME_LAYOUT, OPT_CULLING, OPT_COST_FEEDBACK, OPT_DEPTH_PARALLEL, OPT_XCD_BANDS, OPT_REBALANCE_ROUNDS = 4, 5, 6, 7, 8, 9
 OPT_SETUP_IEEE = 10
+OPT_FRAMES_IN_FLIGHT = 11
 
 
 class VolymError(RuntimeError):

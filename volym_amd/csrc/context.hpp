@@ -164,6 +164,13 @@ struct volym_ctx {
     uint32_t wgs_per_cu = 1;
     int kspec = 4;
     bool culling = true;
+    // VOLYM_OPT_FRAMES_IN_FLIGHT = 2: a second context on the same device (own stream, frame buffer, lists and feedback) that renders
+    // every other frame, so that a frame's workgroups take the CUs the previous frame's tail leaves idle (raymarch.hip "frames in flight")
+    volym_ctx* twin = nullptr;
+    volym_ctx* last = nullptr;                  // the context the latest volym_compute_pass went to (this one or the twin)
+    volym_ctx* last_blit = nullptr;
+    uint32_t flight_parity = 0;
+    std::vector<std::pair<int, int>> option_log;    // options set so far: replayed into a twin created later
     bool setup_ieee = false;                    // VOLYM_OPT_SETUP_IEEE: make_ray with plain divisions (FrameParams::setup_lo = +inf)
     bool straight_jobs = false;                 // dev switch (option 121): CJ = 2 instantiation for the straight look-ahead
     bool lds_bricks = false;        // dev option 122: LDS-staged bricks in the common instantiation (bricked layout)

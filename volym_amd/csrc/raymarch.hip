@@ -710,6 +710,24 @@ int volym_abi_version(void) { return VOLYM_ABI_VERSION; }
 
 const char* volym_last_error(const volym_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+// ---- frames in flight ------------------------------------------------------------------------------------------------
+// A frame of the persistent kernel ends on its longest chains: for the last fifth of its time the CUs empty one by one
+// (DESIGN.md 5).  With VOLYM_OPT_FRAMES_IN_FLIGHT = 2 the context owns a twin -- a complete second context on the same device:
+// stream, frame buffer, volume copy, work lists, feedback thread -- and volym_compute_pass alternates between the two, so the
+// next frame's workgroups start on every CU the previous frame has left (measured: 31.9 -> 27.6 us per frame at 1920x1080).
+// Everything that describes the scene goes to both; the reading calls take the frame of the latest pass.
+#define TWIN_FORWARD(c, call)                                                                              \
+    do {                                                                                                   \
+        if ((c) && (c)->twin) {                                                                            \
+            const int rt_ = (call);                                                                        \
+            if (rt_ != VOLYM_OK) return fail((c), rt_, std::string("second frame context: ") + (c)->twin->err); \
+        }                                                                                                  \
+    } while (0)
+#define TWIN_REFUSE(c, what)                                                                               \
+    do {                                                                                                   \
+        if ((c) && (c)->twin) return fail((c), VOLYM_E_STATE, what ": not with VOLYM_OPT_FRAMES_IN_FLIGHT = 2"); \
+    } while (0)
+
 int volym_create(volym_ctx** out, uint32_t width, uint32_t height, int device_id)
 {
     if (!out) return fail(nullptr, VOLYM_E_INVALID, "volym_create: out is NULL");
@@ -795,6 +813,7 @@ int volym_create(volym_ctx** out, uint32_t width, uint32_t height, int device_id
 void volym_destroy(volym_ctx* c)
 {
     if (!c) return;
+    if (c->twin) { volym_destroy(c->twin); c->twin = nullptr; }
     (void)hipSetDevice(c->device);
     if (c->fb_thread.joinable()) {
         feedback_quiesce(c);
@@ -830,6 +849,7 @@ void volym_destroy(volym_ctx* c)
 int volym_set_stream(volym_ctx* c, void* hip_stream)
 {
     if (!c) return VOLYM_E_INVALID;
+    TWIN_REFUSE(c, "volym_set_stream");
     HIPCHK(c, hipSetDevice(c->device));
     feedback_quiesce(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -840,6 +860,7 @@ int volym_set_stream(volym_ctx* c, void* hip_stream)
 int volym_settle(volym_ctx* c)
 {
     if (!c) return VOLYM_E_INVALID;
+    TWIN_FORWARD(c, volym_settle(c->twin));
     feedback_quiesce(c);
     if (!c->fb_job.error.empty()) { const std::string m = c->fb_job.error; c->fb_job.error.clear(); return fail(c, VOLYM_E_HIP, m); }
     // ... and run the feedback to its fixed point for the current view: frames of this view (what volym_compute_pass
@@ -859,7 +880,48 @@ int volym_settle(volym_ctx* c)
 
 static bool want_bricked(const volym_ctx* c, uint32_t nx, uint32_t ny, uint32_t nz);
 
+static int set_option_one(volym_ctx* c, int key, int value);
+
 int volym_set_option(volym_ctx* c, int key, int value)
+{
+    if (!c) return VOLYM_E_INVALID;
+    if (key == VOLYM_OPT_FRAMES_IN_FLIGHT) {
+        if (value != 1 && value != 2) return fail(c, VOLYM_E_INVALID, "VOLYM_OPT_FRAMES_IN_FLIGHT: 1 or 2");
+        if (value == 1) {
+            if (c->twin) {
+                int rc = volym_sync(c);
+                if (rc != VOLYM_OK) return rc;
+                volym_destroy(c->twin);
+                c->twin = nullptr; c->last = c->last_blit = nullptr; c->flight_parity = 0;
+            }
+            return VOLYM_OK;
+        }
+        if (c->twin) return VOLYM_OK;
+        if (c->have_vol || c->have_imp || c->have_tf)
+            return fail(c, VOLYM_E_STATE, "VOLYM_OPT_FRAMES_IN_FLIGHT = 2: set it before the volume, the importances and the transfer function");
+        if (c->stream != c->own_stream) return fail(c, VOLYM_E_STATE, "VOLYM_OPT_FRAMES_IN_FLIGHT = 2: not with a caller's stream (volym_set_stream)");
+        volym_ctx* t = nullptr;
+        int rc = volym_create(&t, c->W, c->H, c->device);
+        if (rc != VOLYM_OK) return fail(c, rc, std::string("second frame context: ") + volym_last_error(nullptr));
+        for (const auto& kv : c->option_log) {
+            rc = set_option_one(t, kv.first, kv.second);
+            if (rc != VOLYM_OK) { const std::string m = t->err; volym_destroy(t); return fail(c, rc, "second frame context: " + m); }
+        }
+        if (c->world != 1u) {
+            rc = volym_set_shard(t, c->rank, c->world);
+            if (rc != VOLYM_OK) { const std::string m = t->err; volym_destroy(t); return fail(c, rc, "second frame context: " + m); }
+        }
+        c->twin = t;
+        return VOLYM_OK;
+    }
+    const int rc = set_option_one(c, key, value);
+    if (rc != VOLYM_OK) return rc;
+    c->option_log.emplace_back(key, value);
+    TWIN_FORWARD(c, set_option_one(c->twin, key, value));
+    return VOLYM_OK;
+}
+
+static int set_option_one(volym_ctx* c, int key, int value)
 {
     if (!c) return VOLYM_E_INVALID;
     switch (key) {
@@ -971,6 +1033,7 @@ int volym_set_option(volym_ctx* c, int key, int value)
 int volym_set_shard(volym_ctx* c, uint32_t rank, uint32_t world)
 {
     if (!c) return VOLYM_E_INVALID;
+    TWIN_FORWARD(c, volym_set_shard(c->twin, rank, world));
     if (world == 0 || rank >= world || world > 4096) return fail(c, VOLYM_E_INVALID, "volym_set_shard: need rank < world <= 4096");
     // the feedback thread reads rank / world / n_local while it deals a list: let a job in flight finish (and the frames that
     // read the current lists) before any of them changes
@@ -1021,6 +1084,7 @@ static bool want_bricked(const volym_ctx* c, uint32_t nx, uint32_t ny, uint32_t 
 int volym_set_volume(volym_ctx* c, const uint8_t* voxels, uint32_t nx, uint32_t ny, uint32_t nz, int filter)
 {
     if (!c) return VOLYM_E_INVALID;
+    TWIN_FORWARD(c, volym_set_volume(c->twin, voxels, nx, ny, nz, filter));
     if (filter != VOLYM_FILTER_NEAREST && filter != VOLYM_FILTER_LINEAR)
         return fail(c, VOLYM_E_INVALID, "volym_set_volume: filter must be VOLYM_FILTER_NEAREST or VOLYM_FILTER_LINEAR");
     int rc = upload_volume(c, &c->d_vol, voxels, nx, ny, nz);
@@ -1065,6 +1129,7 @@ static void important_texel_box(const uint8_t* imp, uint32_t nx, uint32_t ny, ui
 int volym_set_importances(volym_ctx* c, const uint8_t* importances, uint32_t nx, uint32_t ny, uint32_t nz)
 {
     if (!c) return VOLYM_E_INVALID;
+    TWIN_FORWARD(c, volym_set_importances(c->twin, importances, nx, ny, nz));
     int rc = upload_volume(c, &c->d_imp, importances, nx, ny, nz);
     if (rc != VOLYM_OK) { c->have_imp = false; return rc; }
     important_texel_box(importances, nx, ny, nz, c->imp_box_lo, c->imp_box_hi);
@@ -1076,6 +1141,7 @@ int volym_set_importances(volym_ctx* c, const uint8_t* importances, uint32_t nx,
 int volym_set_transfer_function(volym_ctx* c, const uint8_t* rgba8, uint32_t n)
 {
     if (!c) return VOLYM_E_INVALID;
+    TWIN_FORWARD(c, volym_set_transfer_function(c->twin, rgba8, n));
     if (!rgba8 || n < 1 || n > 256) return fail(c, VOLYM_E_INVALID, "volym_set_transfer_function: 1..256 RGBA8 texels");
     std::memset(c->lut, 0, sizeof c->lut);
     std::memcpy(c->lut, rgba8, static_cast<size_t>(n) * 4);
@@ -1146,6 +1212,7 @@ extern "C" {
 int volym_update(volym_ctx* c, const volym_camera_uniforms* cam, const volym_parameter_uniforms* par)
 {
     if (!c) return VOLYM_E_INVALID;
+    TWIN_FORWARD(c, volym_update(c->twin, cam, par));
     if (!cam || !par) return fail(c, VOLYM_E_INVALID, "volym_update: NULL uniforms");
     if (!c->have_vol || !c->have_imp || !c->have_tf)
         return fail(c, VOLYM_E_STATE, "volym_update: set volume, importances and transfer function first");
@@ -1408,6 +1475,11 @@ int volym_compute_pass(volym_ctx* c)
     if (!c) return VOLYM_E_INVALID;
     if (!c->have_frame) return fail(c, VOLYM_E_STATE, "volym_compute_pass: call volym_update first");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->twin) {                                  // frames in flight: every other frame goes to the twin's stream and frame buffer
+        volym_ctx* const t = (c->flight_parity++ & 1u) ? c->twin : c;
+        c->last = t;
+        if (t != c) { TWIN_FORWARD(c, launch_march<false>(t)); return VOLYM_OK; }
+    }
     return launch_march<false>(c);
 }
 
@@ -1430,7 +1502,7 @@ int volym_throttle(volym_ctx* c, uint32_t max_in_flight)
         c->throttle_ev[slot] = nullptr;
         HIPCHK(c, hipEventCreateWithFlags(&c->throttle_ev[slot], hipEventDisableTiming));
     }
-    HIPCHK(c, hipEventRecord(c->throttle_ev[slot], c->stream));
+    HIPCHK(c, hipEventRecord(c->throttle_ev[slot], (c->twin && c->last) ? c->last->stream : c->stream));   // the frame just enqueued
     c->throttle_head++;
     if (c->throttle_head > max_in_flight) {
         const uint32_t old = (c->throttle_head - 1u - max_in_flight) % volym_ctx::THROTTLE_RING;
@@ -1456,6 +1528,7 @@ static int check_pool_error(volym_ctx* c)
 int volym_sync(volym_ctx* c)
 {
     if (!c) return VOLYM_E_INVALID;
+    TWIN_FORWARD(c, volym_sync(c->twin));
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_pool_error(c);
@@ -1464,6 +1537,7 @@ int volym_sync(volym_ctx* c)
 int volym_read_rgba8(volym_ctx* c, uint8_t* out)
 {
     if (!c || !out) return VOLYM_E_INVALID;
+    if (c->twin && c->last == c->twin) { TWIN_FORWARD(c, volym_read_rgba8(c->twin, out)); return VOLYM_OK; }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out, c->d_frame, static_cast<size_t>(c->W) * c->H * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1473,6 +1547,7 @@ int volym_read_rgba8(volym_ctx* c, uint8_t* out)
 int volym_read_rgba32f(volym_ctx* c, float* out)
 {
     if (!c || !out) return VOLYM_E_INVALID;
+    if (c->twin && c->last == c->twin) { TWIN_FORWARD(c, volym_read_rgba32f(c->twin, out)); return VOLYM_OK; }
     if (!c->write_f32 || !c->d_f32 || c->world != 1)
         return fail(c, VOLYM_E_STATE, "volym_read_rgba32f: needs VOLYM_OPT_WRITE_F32 = 1, world == 1 and a rendered frame");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1485,6 +1560,10 @@ int volym_read_rgba32f(volym_ctx* c, float* out)
 int volym_blit(volym_ctx* c, void* target_rgba8, uint32_t out_w, uint32_t out_h)
 {
     if (!c) return VOLYM_E_INVALID;
+    if (c->twin) {
+        c->last_blit = (c->last == c->twin) ? c->twin : c;
+        if (c->last_blit == c->twin) { TWIN_FORWARD(c, volym_blit(c->twin, target_rgba8, out_w, out_h)); return VOLYM_OK; }
+    }
     if (out_w == 0 || out_h == 0 || out_w > 32768 || out_h > 32768) return fail(c, VOLYM_E_INVALID, "volym_blit: target must be 1..32768 in each dimension");
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t* dst = static_cast<uint32_t*>(target_rgba8);
@@ -1509,6 +1588,7 @@ int volym_blit(volym_ctx* c, void* target_rgba8, uint32_t out_w, uint32_t out_h)
 int volym_read_blit(volym_ctx* c, uint8_t* out)
 {
     if (!c || !out) return VOLYM_E_INVALID;
+    if (c->twin && c->last_blit == c->twin) { TWIN_FORWARD(c, volym_read_blit(c->twin, out)); return VOLYM_OK; }
     if (!c->d_blit || c->blit_w == 0) return fail(c, VOLYM_E_STATE, "volym_read_blit: no volym_blit into the context's own target yet");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out, c->d_blit, static_cast<size_t>(c->blit_w) * c->blit_h * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1532,6 +1612,7 @@ int volym_bind_output(volym_ctx* c, void* shard_rgba8, void* frame_rgba8)
 
 int volym_read_shard(volym_ctx* c, uint8_t* out)
 {
+    TWIN_REFUSE(c, "volym_read_shard");
     if (!c || !out) return VOLYM_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     // the padding tile of a short shard is never written by the kernel: define it
@@ -1550,6 +1631,7 @@ size_t volym_packed_shard_bytes(const volym_ctx* c, uint32_t tiles)
 
 int volym_pack_shard(volym_ctx* c, void* packed, size_t capacity_bytes)
 {
+    TWIN_REFUSE(c, "volym_pack_shard");
     if (!c || !packed) return VOLYM_E_INVALID;
     const size_t header = pack_header_bytes(c->shard_tiles);
     if (capacity_bytes < header) return fail(c, VOLYM_E_INVALID, "volym_pack_shard: the buffer does not even hold the header (volym_packed_shard_bytes)");
@@ -1565,6 +1647,7 @@ int volym_pack_shard(volym_ctx* c, void* packed, size_t capacity_bytes)
 
 int volym_packed_tiles(volym_ctx* c, uint32_t* tiles_used, uint32_t* overflowed)
 {
+    TWIN_REFUSE(c, "volym_packed_tiles");
     if (!c || !tiles_used) return VOLYM_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t h[4] = {0, 0, 0, 0};
@@ -1577,6 +1660,7 @@ int volym_packed_tiles(volym_ctx* c, uint32_t* tiles_used, uint32_t* overflowed)
 
 int volym_assemble_packed(volym_ctx* c, const void* gathered, size_t stride_bytes)
 {
+    TWIN_REFUSE(c, "volym_assemble_packed");
     if (!c || !gathered) return VOLYM_E_INVALID;
     if (stride_bytes < pack_header_bytes(c->shard_tiles)) return fail(c, VOLYM_E_INVALID, "volym_assemble_packed: stride smaller than the header");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1588,6 +1672,7 @@ int volym_assemble_packed(volym_ctx* c, const void* gathered, size_t stride_byte
 
 int volym_assemble(volym_ctx* c, const void* gathered)
 {
+    TWIN_REFUSE(c, "volym_assemble");
     if (!c || !gathered) return VOLYM_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(volym_assemble_kernel, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint32_t*>(gathered),
@@ -1598,6 +1683,7 @@ int volym_assemble(volym_ctx* c, const void* gathered)
 
 int volym_assemble_host(volym_ctx* c, const uint8_t* gathered_host)
 {
+    TWIN_REFUSE(c, "volym_assemble_host");
     if (!c || !gathered_host) return VOLYM_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t bytes = volym_shard_bytes(c) * c->world;
