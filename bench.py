@@ -538,6 +538,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": pq_kernel_name if args.kernel == 2 else "volym_raymarch_pool_kernel<false>" if args.kernel == 3 else "volym_raymarch_kernel<%d,false,false>" % args.kernel,
                 "kernel_avg_ms": kernel_ms, "launch_algorithmic_bytes": local_bytes,
+                "throughput_frac": frame_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS,      # algorithmic bytes of the timed loop / its time / peak
+
                 "note": "algorithmic bytes = reference fetch count (n_vol*%d + n_imp) + 4 B/pixel of %s; the 32 MiB working set is "
                         "Infinity-Cache resident, so HBM traffic << algorithmic bytes (DESIGN.md)" % (b_vol, "this rank's launch" if world > 1 else "the launch")
                         + ("; frac and kernel_avg_ms are the kernel's own (back-to-back launches on one stream); ms_per_step is below kernel_avg_ms because the "

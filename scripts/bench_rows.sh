@@ -9,7 +9,7 @@ run() { name=$1; shift; $B "$@" > $OUT/$name.json 2> $OUT/$name.err; python - "$
 import json,sys
 try:
     d=json.load(open(sys.argv[2]))
-    print("%-22s %8.1f us  %8.0f Mrays/s  frac %.3f  kernel %.1f us  check %s" % (sys.argv[1], d["ms_per_step"]*1e3, d["value"] or 0, d["roofline"]["frac"] or 0, d["roofline"]["kernel_avg_ms"]*1e3, d.get("frame_check")))
+    print("%-22s %8.1f us  %8.0f Mrays/s  frac %.3f  kernel %.1f us  (frames in flight %s: throughput frac %.3f)  check %s" % (sys.argv[1], d["ms_per_step"]*1e3, d["value"] or 0, d["roofline"]["frac"] or 0, d["roofline"]["kernel_avg_ms"]*1e3, d.get("frames_in_flight"), d["roofline"].get("throughput_frac") or 0, d.get("frame_check")))
 except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY

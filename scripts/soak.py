@@ -2,7 +2,7 @@
 """Soak test of the asynchronous host path (product library): random view changes, parameter changes, option toggles, settles and
 read-backs for a few minutes; every frame read back must equal the reference frame of its (view, parameters), rendered once by
 a context without cost feedback.  A hang shows as the caller's timeout; a wrong frame as an assertion.
-usage: soak.py [seconds] [seed]"""
+usage: soak.py [seconds] [seed] [frames in flight: 1 | 2]"""
 import os
 import sys
 import time
@@ -13,8 +13,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from volym_amd import _lib, demo, scene, synth  # noqa: E402
 
 
-def main(seconds=None, seed=None):
+def main(seconds=None, seed=None, flight=None):
     seconds = float(seconds if seconds is not None else (sys.argv[1] if len(sys.argv) > 1 else 60.0))
+    flight = int(flight if flight is not None else 1)
     rng = np.random.default_rng(int(seed if seed is not None else (sys.argv[2] if len(sys.argv) > 2 else 1)))
     W, H = 640, 360
     n = 128
@@ -47,6 +48,8 @@ def main(seconds=None, seed=None):
     t_end = time.time() + seconds
     ops = frames = checks = 0
     with demo.GpuContext(W, H, 0) as ctx:
+        if flight == 2:
+            ctx.set_option(_lib.OPT_FRAMES_IN_FLIGHT, 2)     # compute passes alternate between two frame contexts: every check below reads the latest
         ctx.set_volume(vol, dims, 0)
         ctx.set_importances(imp, dims)
         ctx.set_transfer_function(scene.default_lut())
@@ -96,9 +99,9 @@ def main(seconds=None, seed=None):
                 assert d == 0, "view %d: frame differs from its reference by %d" % (cur, d)
                 checks += 1
         ctx.sync()
-    print("soak: %d operations, %d frames, %d frames checked bit-equal, %.0f s: ok" % (ops, frames, checks, seconds))
+    print("soak (%d frame%s in flight): %d operations, %d frames, %d frames checked bit-equal, %.0f s: ok" % (flight, "s" if flight > 1 else "", ops, frames, checks, seconds))
     return ops, frames, checks
 
 
 if __name__ == "__main__":
-    main()
+    main(flight=int(sys.argv[3]) if len(sys.argv) > 3 else 1)

@@ -16,3 +16,5 @@ def test_soak_8_seconds(volym_lib):
     spec.loader.exec_module(mod)
     ops, frames, checks = mod.main(8.0, 7)
     assert ops > 1000 and frames > 1000 and checks > 20
+    ops, frames, checks = mod.main(5.0, 11, 2)          # the same with two frames in flight (VOLYM_OPT_FRAMES_IN_FLIGHT = 2)
+    assert ops > 500 and frames > 500 and checks > 10
