@@ -708,6 +708,11 @@ def test_cli_benchmark_and_run(volym_lib, tmp_path):
     assert len(rows) == 28 and list(rows[0].keys())[:12] == cli.CSV_COLUMNS
     assert [r["algorithm"] for r in rows].count("ImportanceCone") == 12
     assert all(float(r["avg_fps"]) > 0 and float(r["b_alg_bytes_per_frame"]) > 0 for r in rows)
+    out2 = str(tmp_path / "benchmark_results_2.csv")               # the same sweep, frames per wall clock with two frames in flight
+    assert cli.main(["benchmark", "--width", "192", "--height", "144", "--secs", "0.002", "--output", out2, "--frames-in-flight", "2"]) == 0
+    rows2 = list(csv.DictReader(open(out2)))
+    assert len(rows2) == 28 and all(float(r["avg_fps"]) > 0 for r in rows2)
+    assert [r["b_alg_bytes_per_frame"] for r in rows2] == [r["b_alg_bytes_per_frame"] for r in rows]      # the same frames
     shot = str(tmp_path / "shot.png")
     assert cli.main(["run", "simple", "--width", "160", "--height", "90", "--screenshot", shot]) == 0
     img = image.read_png_rgba8(shot)
@@ -729,6 +734,12 @@ def test_cpp_cli_binary(volym_lib, tmp_path):
     assert r.returncode == 0, r.stderr
     rows = list(csv.DictReader(open(out)))
     assert len(rows) == 28 and rows[0]["algorithm"] == "Base" and rows[27]["use_cone"] == "true"
+    out2 = str(tmp_path / "bench2.csv")
+    r = subprocess.run([exe, "benchmark", "--width", "192", "--height", "144", "--secs", "0.002", "--output", out2, "--frames-in-flight", "2"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows2 = list(csv.DictReader(open(out2)))
+    assert len(rows2) == 28 and [x["b_alg_bytes_per_frame"] for x in rows2] == [x["b_alg_bytes_per_frame"] for x in rows]
     ppm = str(tmp_path / "frame.ppm")
     r = subprocess.run([exe, "run", "simple", "--width", "160", "--height", "90", "--output", ppm], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
