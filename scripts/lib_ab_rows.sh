@@ -3,7 +3,7 @@
 # library (files under volym_amd/), interleaved, three times over, on one box: differences of 0.1 us show (boxes differ by 1-2 %)
 set -u
 TAG=$1; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT; : > $OUT/rows.txt
-B="python bench.py --no-cpu-baseline --no-moving-view --steps 200 --warmup 20"
+B="python bench.py --frames-in-flight 1 --no-cpu-baseline --no-moving-view --steps 200 --warmup 20"
 run() { lib=$1; name=$2; shift 2; VOLYM_HIP_LIB=$GRAFT_REPO_ROOT/volym_amd/$lib $B "$@" > $OUT/$name.$lib.json 2> $OUT/$name.$lib.err; python - "$name $lib" $OUT/$name.$lib.json <<'PY' >> $OUT/rows.txt
 import json,sys
 try:

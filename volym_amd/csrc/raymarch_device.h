@@ -779,8 +779,13 @@ __device__ __forceinline__ Ray make_ray_shared(const FrameParams& fp, uint32_t g
     return r;
 }
 
+// SHARED = false: the plain divisions only -- the instantiations that already keep state in scratch (importance rendering, continuous
+// rho) lose more to the fast form's extra live values than they gain (same-box A/B: importance look-ahead 60.3 -> 63.3 us, smoothing
+// and cone +0.7 %, against -0.5 % on the common instantiation): they keep the shader's form
+template <bool SHARED = true>
 __device__ __forceinline__ Ray make_ray(const FrameParams& fp, uint32_t gx, uint32_t gy)
 {
+    if constexpr (!SHARED) return make_ray_ieee(fp, gx, gy);
     bool ok;
     const Ray r = make_ray_shared(fp, gx, gy, ok);
     if (__builtin_expect(__ballot(!ok) == 0ull, 1)) return r;

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(WAVES * 64) void volym_raymarch_pq_kernel(
         Ray ray;
         ray.o = v3(0.0f, 0.0f, 0.0f); ray.d = v3(0.0f, 0.0f, 0.0f); ray.t_entry = 0.0f; ray.t_exit = 0.0f;
         ray.hit = false;
-        if (in_frame) ray = make_ray(fp, gx, gy);
+        if (in_frame) ray = make_ray<TABLE && !IMP && !IR>(fp, gx, gy);     // shared reciprocals where the registers allow (raymarch_device.h)
         {
             const V3 hvec = ray_half_vector(ray.d);
             hh[lane] = make_float4(hvec.x, hvec.y, hvec.z, 0.0f);     // (a depth-parallel quad: four equal entries, owner = the first)
