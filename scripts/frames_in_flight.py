@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Frames of the bench workload alternating over N contexts on one device (each with its own stream and frame buffer):
-the next frame's workgroups take the CUs the previous frame's tail leaves idle.  python3 scripts/frames_in_flight.py [N=2] [FRAMES=2000] [W H]"""
+the next frame's workgroups take the CUs the previous frame's tail leaves idle.  python3 scripts/frames_in_flight.py [N=2] [FRAMES=2000] [W H]
+(VOLYM_FIF_DP=<VOLYM_OPT_DEPTH_PARALLEL value> sets the split threshold of every context)"""
 import os
 import sys
 import time
@@ -20,6 +21,8 @@ st.update()
 ctxs = []
 for _ in range(n_ctx):
     ctx = demo.GpuContext(W, H, 0)
+    if os.environ.get("VOLYM_FIF_DP"):
+        ctx.set_option(_lib.OPT_DEPTH_PARALLEL, int(os.environ["VOLYM_FIF_DP"]))
     ctx.set_volume(vol, dims)
     ctx.set_importances(np.zeros(256 ** 3, np.uint8), dims)
     ctx.set_transfer_function(scene.default_lut())
