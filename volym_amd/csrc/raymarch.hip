@@ -916,7 +916,8 @@ int volym_set_option(volym_ctx* c, int key, int value)
     }
     const int rc = set_option_one(c, key, value);
     if (rc != VOLYM_OK) return rc;
-    c->option_log.emplace_back(key, value);
+    // (the log is what a twin created later starts from: it can only be created before the scene is set)
+    if (!c->twin && !(c->have_vol || c->have_imp || c->have_tf)) c->option_log.emplace_back(key, value);
     TWIN_FORWARD(c, set_option_one(c->twin, key, value));
     return VOLYM_OK;
 }
