@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box, repo root): ROWS="base c5 ..." bash scripts/lib_ab_rows.sh TAG LIB...  -- the same bench rows with several builds of the
-# library (files under volym_amd/), interleaved, three times over, on one box: differences of 0.1 us show (boxes differ by 1-2 %)
+# library (files under volym_amd/), interleaved, three times over, on one box: differences of 0.1 us show (boxes differ by 1-2 %).
+# One frame at a time (--frames-in-flight 1): the comparison is between kernels, and builds older than the option can take part.
 set -u
 TAG=$1; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT; : > $OUT/rows.txt
 B="python bench.py --frames-in-flight 1 --no-cpu-baseline --no-moving-view --steps 200 --warmup 20"
