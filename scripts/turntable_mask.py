@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turntable (0.25 degrees per view, 3 frames in flight) with the development library: per-view tile mask (option 117 = 2) and
-16x16 super fill items (option 107) on and off.  Usage: python3 scripts/turntable_mask.py [W H]"""
+16x16 super fill items (option 107) on and off.  Usage: [FLIGHT=2] [DEG=0.25] python3 scripts/turntable_mask.py [W H]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +10,8 @@ deg = float(os.environ.get("DEG", "0.25"))
 dims = (256,) * 3
 vol = scene.prepare_volume(synth.synth_bonsai(256), dims, True)
 with demo.GpuContext(W, H, 0) as ctx:
+    if os.environ.get("FLIGHT", "1") == "2":
+        ctx.set_option(_lib.OPT_FRAMES_IN_FLIGHT, 2)
     ctx.set_volume(vol, dims, 0); ctx.set_importances(np.zeros(256 ** 3, np.uint8), dims); ctx.set_transfer_function(scene.default_lut())
     st = scene.State.with_parameters(W / H, scene.StateParameters.benchmark().replace(raymarching_step_size=0.01))
     views = []
