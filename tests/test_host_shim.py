@@ -27,6 +27,19 @@ def test_library_exports_every_declared_symbol(volym_lib):
     assert volym_lib.volym_abi_version() == 2
 
 
+def test_option_keys_match_the_header():
+    """Every VOLYM_OPT_* key of include/volym_hip.h has its twin in the ctypes binding, with the same value (and nothing else does)."""
+    from volym_amd import _lib
+    text = open(os.path.join(ROOT, "include", "volym_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    keys = {k: int(v) for k, v in re.findall(r"\bVOLYM_(OPT_[A-Z0-9_]+)\s*=\s*(\d+)", text)}
+    assert len(keys) >= 11 and len(set(keys.values())) == len(keys)
+    for k, v in keys.items():
+        assert getattr(_lib, k) == v, k
+    bound = {k for k in dir(_lib) if k.startswith("OPT_")}
+    assert bound == set(keys), bound ^ set(keys)
+
+
 def test_no_gpu_means_loud_failure(volym_lib):
     """Without a device the product refuses to run (no CPU fallback)."""
     import torch
