@@ -35,11 +35,14 @@ def _solo(W, H, dims, vol, imp, lut, state):
 def test_virtual_ranks_native_loop(volym_lib, world):
     """N virtual ranks on device 0: the assembled frame after 1, 7 and 23 frames of the native loop equals the frame one
     context renders alone; no packed shard overflows; a view change with slack still fits."""
-    from volym_amd import mgpu
+    from volym_amd import _lib, mgpu
     W, H = 310, 170
     dims, vol, imp, lut, state = _scene(W, H)
     full = _solo(W, H, dims, vol, imp, lut, state)
     with mgpu.MultiGpu(W, H, devices=[0] * world, transport=mgpu.COPY) as mg:
+        with pytest.raises(_lib.VolymError) as e:        # frame twins are a single-context option (include/volym_hip.h)
+            mg.set_option(_lib.OPT_FRAMES_IN_FLIGHT, 2)
+        assert e.value.code == _lib.E_STATE
         mg.set_volume(vol, dims, 0)
         mg.set_importances(imp, dims)
         mg.set_transfer_function(lut)
