@@ -521,6 +521,7 @@ def main():
                 "viewport": [W, H], "volume": list(dims), "tile_sharding": "interleaved 16x16 tiles, k %% %d" % world,
                 "virtual_ranks": (world if (procs == 1 and world > 1) else None),
                 "gather": mg_info,
+                "frames_in_flight": (args.frames_in_flight if world == 1 else 1),   # N = 1: VOLYM_OPT_FRAMES_IN_FLIGHT of the timed loop
             },
             "frames_in_flight": (args.frames_in_flight if world == 1 else None),
             "gather_check": gather_check,
